@@ -1,0 +1,109 @@
+/* lwsnet_hip.h -- C ABI of the MI355X (gfx950) LWSNet disparity hot path.
+ *
+ * The reference (PrinceVictor/LWSNet) has no FFI/plugin layer: the path is Python
+ * calling PaddlePaddle ops (models/models.py).  This header is the boundary a
+ * maintainer binds with ctypes from models/models.py; every
+ * entry point names the reference lines it replaces.  Plain pointers and sizes
+ * only; all tensors are float32, contiguous, NCHW, in DEVICE memory unless the
+ * parameter is called `host`.  `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream).  Calls are asynchronous on that stream.
+ *
+ * Every function returns 0 on success or a negative lws_status; the message of
+ * the last failure on the calling thread is lws_last_error().
+ * A handle is NOT thread-safe; use one handle per (process, device, stream).
+ */
+#ifndef LWSNET_HIP_H
+#define LWSNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LWS_ABI_VERSION 1
+
+typedef enum {
+    LWS_OK = 0,
+    LWS_ERR_INVALID = -1,      /* bad argument / unsupported shape (Python shim raises ValueError) */
+    LWS_ERR_HIP = -2,          /* a HIP runtime call failed (RuntimeError) */
+    LWS_ERR_STATE = -3,        /* missing tensor / not finalized (RuntimeError) */
+    LWS_ERR_NOMEM = -4
+} lws_status;
+
+/* Constructor arguments of LWSNet(args): models/models.py:8-14, defaults inference.py:23-26. */
+typedef struct {
+    int32_t maxdisplist[3];   /* {24,5,5}: stage-1 hypotheses, stage-2/3 residual half-range m (D = 2m-1) */
+    int32_t layers_3d;        /* 4 */
+    int32_t channels_3d;      /* 8 */
+    int32_t growth_rate[3];   /* {4,1,1}: c3 of stage i = channels_3d * growth_rate[i] */
+} lws_config;
+
+typedef struct lws_ctx *lws_handle;
+
+int lws_abi_version(void);
+const char *lws_last_error(void);
+
+/* Number of HIP devices visible / name of device `dev` (diagnostics only). */
+int lws_device_count(void);
+
+/* ---- model object: models/models.py:8-26 -------------------------------------------- */
+int lws_create(const lws_config *cfg, lws_handle *out);
+int lws_destroy(lws_handle h);
+
+/* model.set_state_dict (inference.py:45): one call per state-dict entry, HOST pointer.
+ * Keys are the Paddle structured names, e.g. "volume_postprocess.0.1.2.weight"
+ * (lwsnet_amd/weights.py lists all 226).  Keys outside the hot path are stored too
+ * (used by lws_forward once the 2D networks run natively) and unknown keys are an error. */
+int lws_set_tensor(lws_handle h, const char *key, const float *host, const int64_t *shape, int ndim);
+
+/* Folds eval-mode BatchNorm3D into (scale, shift) pairs, packs the Conv3D weights into
+ * MFMA fragment order and uploads them.  Must be called after the last lws_set_tensor
+ * and before any function that takes a handle + stage. */
+int lws_finalize(lws_handle h);
+
+/* Pre-allocates the activation workspace for batches up to B pairs of H x W so that
+ * later calls never allocate (required before hipGraph capture). */
+int lws_reserve(lws_handle h, int B, int H, int W);
+
+/* ---- per-op entry points (each is one kernel launch) --------------------------------- */
+
+/* LWSNet._build_volume_2d, models/models.py:58-76 (stride 1).
+ * cost[b,d,y,x] = sum_c |L[b,c,y,x] - (x>=d ? R[b,c,y,x-d] : 0)|;  L,R [B,C,h,w] -> cost [B,D,h,w]. */
+int lws_volume_l1_shift(const float *L, const float *R, float *cost,
+                        int B, int C, int h, int w, int D, void *stream);
+
+/* forward() glue models/models.py:119-121 + LWSNet._build_volume_2d3 :78-104 + warp :28-55.
+ * prev_disp [B,1,H,W] is the previous stage's full-resolution disparity; the kernel
+ * resizes it to [h,w] (half-pixel bilinear), scales by h/H, and for k = 0..2m-2 samples R at
+ * x - wflow + (k-(m-1)) through the reference's normalise/grid_sample float32 round trip.
+ * L,R [B,C,h,w] -> cost [B,2m-1,h,w].  If wflow_out != NULL the resized flow [B,h,w] is stored. */
+int lws_volume_l1_warp(const float *L, const float *R, const float *prev_disp, float *cost,
+                       float *wflow_out, int B, int C, int h, int w, int H, int W, int m, void *stream);
+
+/* volume_postprocess[stage](cost) + cost, models/models.py:136-138 with post_3dconvs,
+ * models/submodules.py:190-221: 6 x (BatchNorm3D(eval) -> ReLU -> Conv3D 3x3x3 s1 p1) + skip.
+ * cost_in, cost_out [B,D,h,w] (may not alias). */
+int lws_conv3d_stack(lws_handle h, int stage, const float *cost_in, float *cost_out,
+                     int B, int D, int hh, int ww, void *stream);
+
+/* F.softmax(-cost, axis=1) + disparity_regression, models/models.py:142,151-152,167-179.
+ * cost [B,D,h,w] -> disp_low [B,h,w]; hypothesis values are start, start+1, ... */
+int lws_softargmin(const float *cost, float *disp_low, int B, int D, int h, int w, float start, void *stream);
+
+/* models/models.py:145-148,153-156: out = bilinear_resize(disp_low * H / h -> [H,W]) (+ prev).
+ * disp_low [B,h,w]; prev (may be NULL) and out [B,1,H,W]. */
+int lws_upsample_add(const float *disp_low, const float *prev, float *out,
+                     int B, int h, int w, int H, int W, void *stream);
+
+/* ---- whole path: the body of `for scale in range(3)`, models/models.py:115-156 ------ */
+/* featsL/featsR: the three feature maps of feature_extraction (1/8: [B,16,H/8,W/8],
+ * 1/4: [B,16,H/4,W/4], 1/2: [B,8,H/2,W/2]).  pred_out[s] [B,1,H,W] for s = 0..2. */
+int lws_disparity_stages(lws_handle h, const float *const featsL[3], const float *const featsR[3],
+                         int B, int H, int W, float *const pred_out[3], void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LWSNET_HIP_H */

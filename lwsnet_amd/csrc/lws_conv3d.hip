@@ -1,0 +1,545 @@
+// 3D cost-volume filtering: 6 x (BatchNorm3D(eval) -> ReLU -> Conv3D 3x3x3, stride 1, pad 1, no bias)
+// plus the outer skip   /root/reference/models/submodules.py:190-221, models/models.py:136-138.
+//
+// Data layout: the stack's internal activations are channels-last [B, D, h, w, C3] and hold the
+// POST-activation values relu(bn_{j+1}(conv_j(.))) -- the BatchNorm+ReLU of layer j+1 is the epilogue
+// of layer j, so the zero padding of the convolution is a literal zero, exactly as in the reference
+// (padding is applied after BN+ReLU there too).  BN is y = fmaf(x, s, t) with (s, t) folded on the host.
+//
+// Arithmetic contract (identical in oracle/lws_oracle.c, checked bit for bit by tests/test_gpu_parity.py):
+// every output is ONE float32 fma chain from 0 over taps (kd,kh,kw) outer, input channel inner, ascending.
+// v_mfma_f32_16x16x4_f32 computes exactly such a k-ordered chain, so the MFMA kernels keep that contract.
+//
+//   k_conv3d_first  cin = 1  -> C3   VALU (K = 27)
+//   k_conv3d_mid16  C3 % 16 == 0     fp32 MFMA implicit GEMM, M = cout tile, N = 16 voxels along x
+//   k_conv3d_mid8   C3 == 8          fp32 MFMA, M = (x parity, cout) so that all 16 MFMA rows work
+//   k_conv3d_last   C3 -> 1 + skip   VALU (K = 27*C3)
+#include "lws_common.h"
+
+namespace lws {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bn_relu(float x, float s, float t) { return fmaxf(fmaf(x, s, t), 0.0f); }
+
+// =============================================================================================
+// First layer: cost [B,D,h,w] -> act [B,D,h,w,C3].  One thread = one voxel, all C3 outputs.
+// The 27 input taps come straight from L2 (the volume is at most a few MB); weights are broadcast
+// from LDS as [tap][cout].
+// =============================================================================================
+template <int C3>
+__global__ __launch_bounds__(256) void k_conv3d_first(const float *__restrict__ cost,
+                                                      const float *__restrict__ wgt,    // [C3][27]
+                                                      const float *__restrict__ bn0_s,  // BN of this layer [1]
+                                                      const float *__restrict__ bn0_t,
+                                                      const float *__restrict__ bn_s,   // next layer BN [C3]
+                                                      const float *__restrict__ bn_t,
+                                                      float *__restrict__ act, int D, int h, int w)
+{
+    __shared__ __attribute__((aligned(16))) float sW[27 * C3];
+    for (int i = threadIdx.x; i < 27 * C3; i += 256) {
+        int tap = i / C3, co = i - tap * C3;
+        sW[i] = wgt[co * 27 + tap];
+    }
+    __syncthreads();
+    const float s0 = bn0_s[0], t0 = bn0_t[0];
+    const int64_t vol = (int64_t)D * h * w;
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (v >= vol) return;
+    const int x = (int)(v % w);
+    const int y = (int)((v / w) % h);
+    const int d = (int)(v / ((int64_t)w * h));
+    const float *cb = cost + (int64_t)b * vol;
+    float a[27];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                int zd = d + kd - 1, zy = y + kh - 1, zx = x + kw - 1;
+                bool ok = zd >= 0 && zd < D && zy >= 0 && zy < h && zx >= 0 && zx < w;
+                float val = 0.0f;
+                if (ok) val = bn_relu(cb[((int64_t)zd * h + zy) * w + zx], s0, t0);
+                a[(kd * 3 + kh) * 3 + kw] = val;
+            }
+    float *out = act + ((int64_t)b * vol + v) * C3;
+#pragma unroll
+    for (int c0 = 0; c0 < C3; c0 += 4) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const float4 wv = *reinterpret_cast<const float4 *>(&sW[tap * C3 + c0]);
+            acc[0] = fmaf(a[tap], wv.x, acc[0]);
+            acc[1] = fmaf(a[tap], wv.y, acc[1]);
+            acc[2] = fmaf(a[tap], wv.z, acc[2]);
+            acc[3] = fmaf(a[tap], wv.w, acc[3]);
+        }
+        const float4 s = *reinterpret_cast<const float4 *>(bn_s + c0);
+        const float4 t = *reinterpret_cast<const float4 *>(bn_t + c0);
+        float4 o;
+        o.x = bn_relu(acc[0], s.x, t.x);
+        o.y = bn_relu(acc[1], s.y, t.y);
+        o.z = bn_relu(acc[2], s.z, t.z);
+        o.w = bn_relu(acc[3], s.w, t.w);
+        *reinterpret_cast<float4 *>(out + c0) = o;
+    }
+}
+
+// =============================================================================================
+// Middle layers, C3 a multiple of 16 (stage 1: C3 = 32).
+//
+// Implicit GEMM  Out^T[cout, voxel] = sum_{tap, cin} W[cout, (tap,cin)] * X[(tap,cin), voxel]
+// on v_mfma_f32_16x16x4_f32:  A (16 x 4) = weights of 16 output channels, B (4 x 16) = activations of 16
+// consecutive voxels along x, K = 4 input channels of one tap per instruction.
+//
+// Workgroup = 4 waves = an output tile of TD x TY rows of 16 voxels.  The input halo tile
+// (TD+2)(TY+2)(18) voxels is staged once in LDS, channels-last with a padded voxel stride of C3+4
+// dwords (ds_read_b128 of 16 neighbouring voxels then spreads over the banks).  Inside every
+// 16-channel group the LDS image is 4x4-transposed: dword 4g+j of the group holds channel 4j+g, so the
+// ONE ds_read_b128 of lane (n, g) yields its B operand for the 4 MFMAs j = 0..3 of the group and MFMA j
+// sums channels 4j..4j+3 in order -- the natural ascending-channel chain.  The transpose is free: the
+// staging thread loads the 16 channels of a voxel as 4 float4 and writes 4 float4.
+//
+// Weights are pre-packed on the host in A-fragment order [tap][q][mt][lane][j] (1 KiB per wave load) and
+// streamed from L2 straight into VGPRs, one (tap, 16-channel group) step ahead of the MFMAs; every wave
+// of every workgroup reads the same 27*C3*C3*4 bytes, so they stay L2/L1-resident.
+// Each wave owns TD*TY/4 rows x all C3/16 output-channel tiles: (TD*TY/4)*(C3/16) independent
+// accumulator chains, which covers the 40-cycle dependent-issue latency of the 32-cycle MFMA.
+// =============================================================================================
+template <int C3, int TD, int TY>
+struct Mid16Cfg {
+    static constexpr int MT = C3 / 16;          // output-channel tiles
+    static constexpr int Q = C3 / 16;           // input-channel groups per tap
+    static constexpr int ROWS = TD * TY;
+    static constexpr int RW = ROWS / 4;         // rows per wave
+    static constexpr int HD = TD + 2, HY = TY + 2, HX = 18;
+    static constexpr int VS = C3 + 4;           // LDS voxel stride in dwords
+    static constexpr int NVOX = HD * HY * HX;
+    static constexpr int LDS_BYTES = NVOX * VS * 4;
+    static_assert(ROWS % 4 == 0, "rows must split over 4 waves");
+};
+
+template <int C3, int TD, int TY>
+__global__ __launch_bounds__(256) void k_conv3d_mid16(const float *__restrict__ in,     // [B,D,h,w,C3]
+                                                      const float4 *__restrict__ wpk,   // packed A fragments
+                                                      const float *__restrict__ bn_s,   // next layer BN [C3]
+                                                      const float *__restrict__ bn_t,
+                                                      float *__restrict__ out, int D, int h, int w,
+                                                      int tiles_x, int tiles_y)
+{
+    using Cfg = Mid16Cfg<C3, TD, TY>;
+    constexpr int MT = Cfg::MT, Q = Cfg::Q, RW = Cfg::RW, HY = Cfg::HY, HX = Cfg::HX, VS = Cfg::VS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    int tile = blockIdx.x;
+    const int tx = tile % tiles_x;
+    tile /= tiles_x;
+    const int ty = tile % tiles_y;
+    const int td = tile / tiles_y;
+    const int b = blockIdx.y;
+    const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
+    const float *inb = in + (int64_t)b * D * h * w * C3;
+
+    // ---- stage the halo tile: one item = (voxel, 16-channel group) = 64 contiguous bytes ----
+    for (int it = tid; it < Cfg::NVOX * Q; it += 256) {
+        const int q = it % Q, v = it / Q;
+        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0;
+        if (gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w) {
+            const float4 *src = reinterpret_cast<const float4 *>(inb + (((int64_t)gd * h + gy) * w + gx) * C3 + q * 16);
+            c0 = src[0];
+            c1 = src[1];
+            c2 = src[2];
+            c3 = src[3];
+        }
+        float4 *dst = reinterpret_cast<float4 *>(lds + v * VS + q * 16);
+        dst[0] = make_float4(c0.x, c1.x, c2.x, c3.x);
+        dst[1] = make_float4(c0.y, c1.y, c2.y, c3.y);
+        dst[2] = make_float4(c0.z, c1.z, c2.z, c3.z);
+        dst[3] = make_float4(c0.w, c1.w, c2.w, c3.w);
+    }
+    __syncthreads();
+
+    floatx4 acc[RW][MT];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    // per-row LDS base of this lane: voxel (rd, ry, n) of the halo tile, channel quad g
+    int rbase[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = wave * RW + r;
+        const int rd = row / TY, ry = row % TY;
+        rbase[r] = ((rd * HY + ry) * HX + n) * VS + 4 * g;
+    }
+
+    const float4 *wp = wpk + lane;
+    float4 a_nxt[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = wp[mt * 64];
+
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tap = (kd * 3 + kh) * 3 + kw;
+                const int toff = ((kd * HY + kh) * HX + kw) * VS;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    float4 a[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a[mt] = a_nxt[mt];
+                    const int step = tap * Q + q;
+                    if (step + 1 < 27 * Q) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = wp[((step + 1) * MT + mt) * 64];
+                    }
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        const float4 bv = *reinterpret_cast<const float4 *>(lds + rbase[r] + toff + q * 16);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, bv.x, acc[r][mt], 0, 0, 0);
+                            acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, bv.y, acc[r][mt], 0, 0, 0);
+                            acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, bv.z, acc[r][mt], 0, 0, 0);
+                            acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, bv.w, acc[r][mt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: D[i][j]: row i = 4*(lane>>4) + reg = output channel in the tile, col j = lane&15 = voxel.
+    //      Apply the NEXT layer's BatchNorm + ReLU and store 4 consecutive channels of one voxel (16 B).
+    float *outb = out + (int64_t)b * D * h * w * C3;
+    const int gx = x0 + n;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = wave * RW + r;
+        const int gd = d0 + row / TY, gy = y0 + row % TY;
+        if (gd < D && gy < h && gx < w) {
+            float *o = outb + (((int64_t)gd * h + gy) * w + gx) * C3;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int cb = mt * 16 + 4 * g;
+                const float4 s = *reinterpret_cast<const float4 *>(bn_s + cb);
+                const float4 t = *reinterpret_cast<const float4 *>(bn_t + cb);
+                float4 v;
+                v.x = bn_relu(acc[r][mt][0], s.x, t.x);
+                v.y = bn_relu(acc[r][mt][1], s.y, t.y);
+                v.z = bn_relu(acc[r][mt][2], s.z, t.z);
+                v.w = bn_relu(acc[r][mt][3], s.w, t.w);
+                *reinterpret_cast<float4 *>(o + cb) = v;
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// Middle layers, C3 == 8 (stages 2 and 3).
+//
+// With only 8 output channels a 16-row MFMA tile would be half empty.  Instead the 16 rows are
+// (x parity, cout): row i = 8*xpar + cout, column n = voxel pair, output x = x0 + 2n + xpar.  Both
+// parities read the SAME activation x_in = x0 + 2n + t - 1 (t = 0..3), so the B operand is shared and the
+// A operand is W[cout][cin][kd][kh][kw = t - xpar] (zero where t - xpar is outside 0..2: fmaf(0, b, acc)
+// == acc, the chain is unchanged).  K per (kd,kh) is 4 t x 8 cin = 8 MFMAs instead of 3 x 8 / 4 = 6 for
+// half the outputs: 75 % of the MFMA work is useful instead of 50 %.
+// The 72 A fragments (one VGPR each) of a layer stay in registers for the whole kernel; activations are
+// staged in LDS as 8 channel planes [cin][row][34] with an odd plane stride (ds_read_b32 of lanes
+// (g in {0,1}, n) hits 32 different banks).
+// =============================================================================================
+template <int TD, int TY>
+struct Mid8Cfg {
+    static constexpr int ROWS = TD * TY;
+    static constexpr int RW = ROWS / 4;
+    static constexpr int HD = TD + 2, HY = TY + 2, HX = 34;
+    static constexpr int NVOX = HD * HY * HX;
+    static constexpr int PS = (NVOX % 2 == 0) ? NVOX + 1 : NVOX;   // odd plane stride
+    static constexpr int LDS_BYTES = 8 * PS * 4;
+    static_assert(ROWS % 4 == 0, "rows must split over 4 waves");
+};
+
+template <int TD, int TY>
+__global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ in,      // [B,D,h,w,8]
+                                                     const float *__restrict__ wpk,     // [72][64] A fragments
+                                                     const float *__restrict__ bn_s,    // next layer BN [8]
+                                                     const float *__restrict__ bn_t,
+                                                     float *__restrict__ out, int D, int h, int w,
+                                                     int tiles_x, int tiles_y)
+{
+    using Cfg = Mid8Cfg<TD, TY>;
+    constexpr int RW = Cfg::RW, HY = Cfg::HY, HX = Cfg::HX, PS = Cfg::PS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    int tile = blockIdx.x;
+    const int tx = tile % tiles_x;
+    tile /= tiles_x;
+    const int ty = tile % tiles_y;
+    const int td = tile / tiles_y;
+    const int b = blockIdx.y;
+    const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
+    const float *inb = in + (int64_t)b * D * h * w * 8;
+
+    float wa[72];
+#pragma unroll
+    for (int s = 0; s < 72; ++s) wa[s] = wpk[s * 64 + lane];
+
+    // ---- stage: one item = half a voxel (4 channels, 16 B); scatter into 4 channel planes ----
+    for (int it = tid; it < Cfg::NVOX * 2; it += 256) {
+        const int half = it & 1, v = it >> 1;
+        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w)
+            c = *reinterpret_cast<const float4 *>(inb + (((int64_t)gd * h + gy) * w + gx) * 8 + half * 4);
+        float *dst = lds + (half * 4) * PS + v;
+        dst[0] = c.x;
+        dst[PS] = c.y;
+        dst[2 * PS] = c.z;
+        dst[3 * PS] = c.w;
+    }
+    __syncthreads();
+
+    floatx4 acc[RW];
+    int rbase[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        acc[r] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        const int row = wave * RW + r;
+        const int rd = row / TY, ry = row % TY;
+        rbase[r] = g * PS + (rd * HY + ry) * HX + 2 * n;
+    }
+
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int step = ((kd * 3 + kh) * 4 + t) * 2 + half;
+                    const int off = half * 4 * PS + (kd * HY + kh) * HX + t;
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        const float bv = lds[rbase[r] + off];
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], bv, acc[r], 0, 0, 0);
+                    }
+                }
+
+    // ---- epilogue: row i = 4*(lane>>4) + reg -> xpar = (lane>>4)>>1, cout = 4*((lane>>4)&1) + reg ----
+    float *outb = out + (int64_t)b * D * h * w * 8;
+    const int xpar = g >> 1, cb = 4 * (g & 1);
+    const int gx = x0 + 2 * n + xpar;
+    const float4 s = *reinterpret_cast<const float4 *>(bn_s + cb);
+    const float4 t = *reinterpret_cast<const float4 *>(bn_t + cb);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = wave * RW + r;
+        const int gd = d0 + row / TY, gy = y0 + row % TY;
+        if (gd < D && gy < h && gx < w) {
+            float4 v;
+            v.x = bn_relu(acc[r][0], s.x, t.x);
+            v.y = bn_relu(acc[r][1], s.y, t.y);
+            v.z = bn_relu(acc[r][2], s.z, t.z);
+            v.w = bn_relu(acc[r][3], s.w, t.w);
+            *reinterpret_cast<float4 *>(outb + (((int64_t)gd * h + gy) * w + gx) * 8 + cb) = v;
+        }
+    }
+}
+
+// =============================================================================================
+// Last layer: act [B,D,h,w,C3] -> cost_out [B,D,h,w] = conv(act) + cost_in   (models.py:137).
+// One thread = one voxel; 27 x C3 fma chain; the weights are [tap][cin] and indexed uniformly, so
+// they come through the scalar cache.
+// =============================================================================================
+template <int C3>
+__global__ __launch_bounds__(256) void k_conv3d_last(const float *__restrict__ act,
+                                                     const float *__restrict__ wgt,   // [27][C3]
+                                                     const float *__restrict__ skip,
+                                                     float *__restrict__ cost_out, int D, int h, int w)
+{
+    const int64_t vol = (int64_t)D * h * w;
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (v >= vol) return;
+    const int x = (int)(v % w);
+    const int y = (int)((v / w) % h);
+    const int d = (int)(v / ((int64_t)w * h));
+    const float *ab = act + (int64_t)b * vol * C3;
+    float acc = 0.0f;
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd) {
+        const int zd = d + kd - 1;
+        if (zd < 0 || zd >= D) continue;
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+            const int zy = y + kh - 1;
+            if (zy < 0 || zy >= h) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int zx = x + kw - 1;
+                const int tap = (kd * 3 + kh) * 3 + kw;
+                if (zx >= 0 && zx < w) {
+                    const float4 *p = reinterpret_cast<const float4 *>(ab + (((int64_t)zd * h + zy) * w + zx) * C3);
+                    const float *wt = wgt + tap * C3;
+#pragma unroll
+                    for (int c4 = 0; c4 < C3 / 4; ++c4) {
+                        const float4 a = p[c4];
+                        acc = fmaf(a.x, wt[c4 * 4 + 0], acc);
+                        acc = fmaf(a.y, wt[c4 * 4 + 1], acc);
+                        acc = fmaf(a.z, wt[c4 * 4 + 2], acc);
+                        acc = fmaf(a.w, wt[c4 * 4 + 3], acc);
+                    }
+                }
+            }
+        }
+    }
+    const int64_t o = (int64_t)b * vol + v;
+    cost_out[o] = acc + skip[o];
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+size_t packed_mid_weight_floats(int c3)
+{
+    if (c3 == 8) return 72 * 64;
+    return (size_t)27 * c3 * c3;
+}
+
+// w: [cout][cin][27] (Conv3D weight [Cout,Cin,3,3,3] flattened)
+void pack_mid_weights(const float *w, int c3, float *out)
+{
+    if (c3 == 8) {
+        for (int kd = 0; kd < 3; ++kd)
+            for (int kh = 0; kh < 3; ++kh)
+                for (int t = 0; t < 4; ++t)
+                    for (int half = 0; half < 2; ++half) {
+                        const int step = ((kd * 3 + kh) * 4 + t) * 2 + half;
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int i = lane & 15, g = lane >> 4;
+                            const int xpar = i >> 3, cout = i & 7;
+                            const int cin = 4 * half + g;
+                            const int kw = t - xpar;
+                            float v = 0.0f;
+                            if (kw >= 0 && kw <= 2) v = w[(cout * 8 + cin) * 27 + (kd * 3 + kh) * 3 + kw];
+                            out[step * 64 + lane] = v;
+                        }
+                    }
+        return;
+    }
+    const int Q = c3 / 16, MT = c3 / 16;
+    for (int tap = 0; tap < 27; ++tap)
+        for (int q = 0; q < Q; ++q)
+            for (int mt = 0; mt < MT; ++mt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = lane & 15, g = lane >> 4;
+                        const int cout = 16 * mt + m, cin = 16 * q + 4 * j + g;
+                        out[((((size_t)tap * Q + q) * MT + mt) * 64 + lane) * 4 + j] = w[((size_t)cout * c3 + cin) * 27 + tap];
+                    }
+}
+
+template <int C3>
+static void first_launch(const Stage3d &s, const float *cost, float *act, int B, int D, int h, int w, hipStream_t st)
+{
+    const int64_t vol = (int64_t)D * h * w;
+    dim3 grid((unsigned)((vol + 255) / 256), B), block(256);
+    hipLaunchKernelGGL(k_conv3d_first<C3>, grid, block, 0, st, cost, s.layers[0].w, s.layers[0].bn_s,
+                       s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act, D, h, w);
+}
+
+int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int B, int D, int h, int w,
+                        hipStream_t st)
+{
+    switch (s.c3) {
+        case 8: first_launch<8>(s, cost, act_out, B, D, h, w, st); break;
+        case 16: first_launch<16>(s, cost, act_out, B, D, h, w, st); break;
+        case 32: first_launch<32>(s, cost, act_out, B, D, h, w, st); break;
+        default: set_error("conv3d: unsupported channel count %d (8, 16, 32)", s.c3); return LWS_ERR_INVALID;
+    }
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+template <int C3, int TD, int TY>
+static int mid16_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w,
+                        hipStream_t st)
+{
+    using Cfg = Mid16Cfg<C3, TD, TY>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3d_mid16<C3, TD, TY>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles_x = cdiv(w, 16), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
+    dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
+    hipLaunchKernelGGL((k_conv3d_mid16<C3, TD, TY>), grid, block, Cfg::LDS_BYTES, st, in,
+                       reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
+                       s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y);
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+template <int TD, int TY>
+static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w,
+                       hipStream_t st)
+{
+    using Cfg = Mid8Cfg<TD, TY>;
+    const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
+    dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
+    hipLaunchKernelGGL((k_conv3d_mid8<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w,
+                       s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y);
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+// layer = 1 .. layers_3d (the C3 -> C3 convolutions)
+int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *act_out, int B, int D, int h,
+                      int w, hipStream_t st)
+{
+    switch (s.c3) {
+        case 8: return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+        case 16: return mid16_launch<16, 3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+        case 32: return mid16_launch<32, 3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+        default: set_error("conv3d: unsupported channel count %d (8, 16, 32)", s.c3); return LWS_ERR_INVALID;
+    }
+}
+
+template <int C3>
+static void last_launch(const Stage3d &s, const float *act, const float *skip, float *out, int B, int D, int h,
+                        int w, hipStream_t st)
+{
+    const int64_t vol = (int64_t)D * h * w;
+    dim3 grid((unsigned)((vol + 255) / 256), B), block(256);
+    hipLaunchKernelGGL(k_conv3d_last<C3>, grid, block, 0, st, act, s.layers.back().w, skip, out, D, h, w);
+}
+
+int launch_conv3d_last(const Stage3d &s, const float *act_in, const float *cost_skip, float *cost_out, int B,
+                       int D, int h, int w, hipStream_t st)
+{
+    switch (s.c3) {
+        case 8: last_launch<8>(s, act_in, cost_skip, cost_out, B, D, h, w, st); break;
+        case 16: last_launch<16>(s, act_in, cost_skip, cost_out, B, D, h, w, st); break;
+        case 32: last_launch<32>(s, act_in, cost_skip, cost_out, B, D, h, w, st); break;
+        default: set_error("conv3d: unsupported channel count %d (8, 16, 32)", s.c3); return LWS_ERR_INVALID;
+    }
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+}  // namespace lws

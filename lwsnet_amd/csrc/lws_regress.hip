@@ -1,0 +1,83 @@
+// Soft-argmin regression and disparity upsampling (HBM-bound, float32, -ffp-contract=off).
+//
+//   k_softargmin    <- F.softmax(-cost, axis=1) + disparity_regression
+//                      /root/reference/models/models.py:142,151-152,167-179
+//   k_upsample_add  <- models.py:145-148,153-156
+#include "lws_common.h"
+#include "lws_device_math.h"
+
+namespace lws {
+
+// One thread per pixel; the D costs of a pixel are D coalesced plane reads (L1/L2 keep the
+// three passes on chip: a wave's footprint is D x 256 B).  p_k = e_k / S is a correctly
+// rounded division, as in the literal softmax followed by the expectation.
+__global__ __launch_bounds__(256) void k_softargmin(const float *__restrict__ cost, float *__restrict__ low,
+                                                    int64_t plane, int D, float start)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= plane) return;
+    const float *c = cost + (int64_t)b * D * plane + p;
+    low[(int64_t)b * plane + p] = softargmin_pixel(c, plane, D, start);
+}
+
+int launch_softargmin(const float *cost, float *low, int B, int D, int h, int w, float start, hipStream_t st)
+{
+    const int64_t plane = (int64_t)h * w;
+    dim3 grid((unsigned)((plane + 255) / 256), B), block(256);
+    hipLaunchKernelGGL(k_softargmin, grid, block, 0, st, cost, low, plane, D, start);
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+__device__ __forceinline__ void src_index_up(int dst, float ratio, int in, int &i0, int &i1, float &l0, float &l1)
+{
+    float s = ratio * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0.0f) s = 0.0f;
+    int a = (int)s;
+    if (a > in - 1) a = in - 1;
+    i0 = a;
+    i1 = (a < in - 1) ? a + 1 : a;
+    l1 = s - (float)a;
+    l0 = 1.0f - l1;
+}
+
+// One thread per full-resolution pixel; the low-resolution map is tiny and L2-resident.
+__global__ __launch_bounds__(256) void k_upsample_add(const float *__restrict__ low,
+                                                      const float *__restrict__ prev,
+                                                      float *__restrict__ out, int h, int w, int H, int W,
+                                                      float mul_a, float mul_b)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const float rh = (float)h / (float)H, rw = (float)w / (float)W;
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    src_index_up(y, rh, h, y0, y1, hy0, hy1);
+    src_index_up(x, rw, w, x0, x1, wx0, wx1);
+    const float *p = low + (int64_t)b * h * w;
+    float p00 = (p[(int64_t)y0 * w + x0] * mul_a) * mul_b;
+    float p01 = (p[(int64_t)y0 * w + x1] * mul_a) * mul_b;
+    float p10 = (p[(int64_t)y1 * w + x0] * mul_a) * mul_b;
+    float p11 = (p[(int64_t)y1 * w + x1] * mul_a) * mul_b;
+    float top = p00 * wx0 + p01 * wx1;
+    float bot = p10 * wx0 + p11 * wx1;
+    float v = hy0 * top + hy1 * bot;
+    const int64_t o = ((int64_t)b * H + y) * W + x;
+    if (prev != nullptr) v = v + prev[o];
+    out[o] = v;
+}
+
+int launch_upsample_add(const float *low, const float *prev, float *out, int B, int h, int w, int H, int W,
+                        hipStream_t st)
+{
+    dim3 grid(cdiv(W, 64), cdiv(H, 4), B), block(64, 4);
+    hipLaunchKernelGGL(k_upsample_add, grid, block, 0, st, low, prev, out, h, w, H, W, (float)H,
+                       1.0f / (float)h);
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+}  // namespace lws

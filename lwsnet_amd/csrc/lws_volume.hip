@@ -1,0 +1,183 @@
+// Cost-volume kernels (HBM/L2-bound; float32; compiled with -ffp-contract=off so that every
+// operation below is the IEEE operation written -- the C oracle performs the same sequence).
+//
+//   k_volume_l1_shift  <- LWSNet._build_volume_2d   /root/reference/models/models.py:58-76
+//   k_volume_l1_warp   <- forward() glue :119-121 + _build_volume_2d3 :78-104 + warp :28-55
+#include "lws_common.h"
+
+namespace lws {
+
+// ---------------------------------------------------------------------------------------------
+// Stage-1 volume.  One workgroup = one image row segment of 64 pixels; the right-feature row
+// segment [x0-(D-1), x0+63] of all C channels is staged once in LDS (zero for x < 0: the
+// reference treats the occluded columns as |L - 0|, models.py:71), the left features of a
+// pixel live in registers, and the 4 waves split the D hypotheses.  Global reads and writes
+// are coalesced along W.
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void k_volume_l1_shift(const float *__restrict__ L,
+                                                         const float *__restrict__ R,
+                                                         float *__restrict__ cost, int h, int w, int D)
+{
+    extern __shared__ float sR[];   // [C][64 + D - 1]
+    const int x0 = blockIdx.x * 64, y = blockIdx.y, b = blockIdx.z;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int span = 64 + D - 1;
+    const int64_t plane = (int64_t)h * w;
+    const float *Rb = R + (int64_t)b * C * plane + (int64_t)y * w;
+    for (int i = ty * 64 + tx; i < C * span; i += 256) {
+        int c = i / span, p = i - c * span;
+        int x = x0 - (D - 1) + p;
+        sR[i] = (x >= 0 && x < w) ? Rb[(int64_t)c * plane + x] : 0.0f;
+    }
+    __syncthreads();
+    const int x = x0 + tx;
+    if (x >= w) return;
+    float l[C];
+    const float *Lb = L + (int64_t)b * C * plane + (int64_t)y * w + x;
+#pragma unroll
+    for (int c = 0; c < C; ++c) l[c] = Lb[(int64_t)c * plane];
+    float *out = cost + (int64_t)b * D * plane + (int64_t)y * w + x;
+    for (int d = ty; d < D; d += 4) {
+        const float *r = sR + tx + (D - 1) - d;
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc = acc + fabsf(l[c] - r[c * span]);
+        out[(int64_t)d * plane] = acc;
+    }
+}
+
+int launch_volume_l1_shift(const float *L, const float *R, float *cost, int B, int C, int h, int w, int D,
+                           hipStream_t st)
+{
+    dim3 grid(cdiv(w, 64), h, B), block(64, 4);
+    size_t lds = (size_t)C * (64 + D - 1) * sizeof(float);
+    switch (C) {
+        case 8: hipLaunchKernelGGL(k_volume_l1_shift<8>, grid, block, lds, st, L, R, cost, h, w, D); break;
+        case 16: hipLaunchKernelGGL(k_volume_l1_shift<16>, grid, block, lds, st, L, R, cost, h, w, D); break;
+        case 32: hipLaunchKernelGGL(k_volume_l1_shift<32>, grid, block, lds, st, L, R, cost, h, w, D); break;
+        default: set_error("volume_l1_shift: unsupported channel count %d (8, 16, 32)", C); return LWS_ERR_INVALID;
+    }
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Half-pixel bilinear source index (F.interpolate align_corners=False, align_mode=0).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void src_index(int dst, float ratio, int in, int &i0, int &i1, float &l0, float &l1)
+{
+    float s = ratio * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0.0f) s = 0.0f;
+    int a = (int)s;
+    if (a > in - 1) a = in - 1;
+    i0 = a;
+    i1 = (a < in - 1) ? a + 1 : a;
+    l1 = s - (float)a;
+    l0 = 1.0f - l1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage-2/3 residual volume.  One thread = one (pixel, hypothesis k); grid.y = k so that a
+// wave reads 64 consecutive pixels of one row.  The 9x expansion of L, R and disp the
+// reference materialises (models.py:85-99) is pure index arithmetic here.  The previous
+// disparity is resized on the fly (4 taps); the right features are gathered straight from
+// L2/L1: neighbouring lanes sample neighbouring columns because the flow is smooth.
+// The south taps are only touched when iy is not an exact integer (a wave-uniform branch,
+// exact because x + 0*v == x for finite v).
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict__ L,
+                                                        const float *__restrict__ R,
+                                                        const float *__restrict__ prev,
+                                                        float *__restrict__ cost,
+                                                        float *__restrict__ wflow_out, int h, int w,
+                                                        int H, int W, int m, float mul_a, float mul_b)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y, b = blockIdx.z;
+    const int64_t plane = (int64_t)h * w;
+    if (pix >= plane) return;
+    const int y = pix / w, x = pix - y * w;
+
+    // wflow = resize(prev)[y,x] * float(h) * float32(1/H)            (models.py:119-121)
+    float wf;
+    {
+        const float rh = (float)H / (float)h, rw = (float)W / (float)w;
+        int y0, y1, x0, x1;
+        float hy0, hy1, wx0, wx1;
+        src_index(y, rh, H, y0, y1, hy0, hy1);
+        src_index(x, rw, W, x0, x1, wx0, wx1);
+        const float *p = prev + (int64_t)b * H * W;
+        float top = p[(int64_t)y0 * W + x0] * wx0 + p[(int64_t)y0 * W + x1] * wx1;
+        float bot = p[(int64_t)y1 * W + x0] * wx0 + p[(int64_t)y1 * W + x1] * wx1;
+        wf = hy0 * top + hy1 * bot;
+        wf = wf * mul_a;
+        wf = wf * mul_b;
+    }
+    if (wflow_out != nullptr && k == 0) wflow_out[(int64_t)b * plane + pix] = wf;
+
+    const float rw = 1.0f / (float)(w - 1 > 1 ? w - 1 : 1);
+    const float rh = 1.0f / (float)(h - 1 > 1 ? h - 1 : 1);
+    const float fw1 = (float)(w - 1), fh1 = (float)(h - 1);
+    const float sk = (float)(k - (m - 1));
+    float delta = wf - sk;                              // models.py:93
+    float vx = (float)x - delta;                        // :45
+    float gx = (2.0f * vx) * rw - 1.0f;                 // :47
+    float gy = (2.0f * (float)y) * rh - 1.0f;           // :48
+    float ix = ((gx + 1.0f) / 2.0f) * fw1;              // grid_sample un-normalise (align_corners=True)
+    float iy = ((gy + 1.0f) / 2.0f) * fh1;
+    float fx0 = floorf(ix), fy0 = floorf(iy);
+    float fx1 = fx0 + 1.0f, fy1 = fy0 + 1.0f;
+    float w_nw = (fx1 - ix) * (fy1 - iy);
+    float w_ne = (ix - fx0) * (fy1 - iy);
+    float w_sw = (fx1 - ix) * (iy - fy0);
+    float w_se = (ix - fx0) * (iy - fy0);
+    float cx = fx0 < -2.0f ? -2.0f : (fx0 > (float)w ? (float)w : fx0);
+    float cy = fy0 < -2.0f ? -2.0f : (fy0 > (float)h ? (float)h : fy0);
+    const int x0 = (int)cx, y0 = (int)cy, x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = (x0 >= 0 && x0 < w), vx1 = (x1 >= 0 && x1 < w);
+    const bool vy0 = (y0 >= 0 && y0 < h), vy1 = (y1 >= 0 && y1 < h);
+    const bool south = (iy - fy0) != 0.0f;              // else w_sw == w_se == 0 exactly
+
+    const float *Lp = L + (int64_t)b * C * plane + pix;
+    const float *Rp = R + (int64_t)b * C * plane;
+    const int64_t o_nw = (int64_t)y0 * w + x0, o_ne = o_nw + 1, o_sw = o_nw + w, o_se = o_sw + 1;
+    float acc = 0.0f;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        const float *rp = Rp + (int64_t)c * plane;
+        float s = 0.0f;
+        if (vy0 && vx0) s = s + rp[o_nw] * w_nw;
+        if (vy0 && vx1) s = s + rp[o_ne] * w_ne;
+        if (south) {
+            if (vy1 && vx0) s = s + rp[o_sw] * w_sw;
+            if (vy1 && vx1) s = s + rp[o_se] * w_se;
+        }
+        float l = Lp[(int64_t)c * plane];
+        acc = acc + fabsf(l - s);                        // :101
+    }
+    cost[((int64_t)b * (2 * m - 1) + k) * plane + pix] = acc;
+}
+
+int launch_volume_l1_warp(const float *L, const float *R, const float *prev, float *cost, float *wflow_out,
+                          int B, int C, int h, int w, int H, int W, int m, hipStream_t st)
+{
+    dim3 grid(cdiv(h * w, 256), 2 * m - 1, B), block(256);
+    const float mul_a = (float)h, mul_b = 1.0f / (float)H;
+    switch (C) {
+        case 8:
+            hipLaunchKernelGGL(k_volume_l1_warp<8>, grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m,
+                               mul_a, mul_b);
+            break;
+        case 16:
+            hipLaunchKernelGGL(k_volume_l1_warp<16>, grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m,
+                               mul_a, mul_b);
+            break;
+        default: set_error("volume_l1_warp: unsupported channel count %d (8, 16)", C); return LWS_ERR_INVALID;
+    }
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+}  // namespace lws

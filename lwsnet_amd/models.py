@@ -1,0 +1,130 @@
+"""Drop-in mirror of the reference model object (/root/reference/models/models.py:7-164).
+
+``LWSNet(args)`` reads the same four namespace fields, ``set_state_dict`` takes the
+same structured keys, and ``model(left, right)`` returns the same list of four
+``[B,1,H,W]`` float32 full-resolution disparity maps.  The three volume stages
+(models.py:115-156) run in the hand-written HIP library behind the C ABI; this class
+only owns device buffers and the call sequence.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, ops, submodules
+from .synth import check_size
+from .weights import state_dict_spec
+
+
+class LWSNet:
+    def __init__(self, args, device=None):
+        self.maxdisplist = [int(v) for v in args.maxdisplist]      # models.py:11-14
+        self.layers_3d = int(args.layers_3d)
+        self.channels_3d = int(args.channels_3d)
+        self.growth_rate = [int(v) for v in args.growth_rate]
+        if len(self.maxdisplist) != 3 or len(self.growth_rate) != 3:
+            raise ValueError("maxdisplist and growth_rate must have three entries (one per volume stage)")
+        self._args = args
+        self._spec = {k: s for k, s, _ in state_dict_spec(args)}
+        self._sd = {}
+        self._params = None
+        self._training = False
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()) \
+            if torch.cuda.is_available() else None
+        lib = _lib.load()                                         # raises if the HIP extension is missing
+        cfg = _lib.LwsConfig((ctypes.c_int32 * 3)(*self.maxdisplist), self.layers_3d, self.channels_3d,
+                             (ctypes.c_int32 * 3)(*self.growth_rate))
+        self._h = ctypes.c_void_p()
+        _lib.check(lib.lws_create(ctypes.byref(cfg), ctypes.byref(self._h)), "lws_create")
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.load().lws_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ---- nn.Layer protocol used by inference.py / train.py ------------------------------------
+    def eval(self):
+        self._training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("lwsnet_amd.LWSNet is inference-only: BatchNorm uses running statistics")
+        return self.eval()
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def parameters(self):
+        return [v for k, v in self._sd.items() if not k.endswith(("._mean", "._variance"))]
+
+    def set_state_dict(self, state_dict):
+        """model.set_state_dict(paddle.load(path)) (inference.py:45): {structured name: array}."""
+        sd = {}
+        for k, v in state_dict.items():
+            if k == "StructuredToParameterName@@":               # bookkeeping entry of paddle.save (2.0rc0)
+                continue
+            if isinstance(v, tuple) and len(v) == 2:               # paddle >= 2.1 stores (name, ndarray)
+                v = v[1]
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            sd[k] = np.ascontiguousarray(np.asarray(v), dtype=np.float32)
+        missing = [k for k in self._spec if k not in sd]
+        if missing:
+            raise KeyError(f"state dict is missing {len(missing)} entries, e.g. {missing[:3]}")
+        lib = _lib.load()
+        with self._device_ctx():
+            for k, v in sd.items():
+                shape = (ctypes.c_int64 * v.ndim)(*v.shape)
+                _lib.check(lib.lws_set_tensor(self._h, k.encode(), v.ctypes.data_as(_lib.c_float_p), shape, v.ndim),
+                           "lws_set_tensor")
+            if self.device is not None:
+                _lib.check(lib.lws_finalize(self._h), "lws_finalize")
+                self._params = submodules.Params(sd, self.device)
+        self._sd = sd
+        return self
+
+    load_dict = set_state_dict
+
+    def _device_ctx(self):
+        if self.device is None:
+            import contextlib
+            return contextlib.nullcontext()
+        return torch.cuda.device(self.device)
+
+    # ---- forward -------------------------------------------------------------------------------
+    def _input(self, x, name):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        if not isinstance(x, torch.Tensor):
+            raise TypeError(f"{name} must be a torch tensor or numpy array")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"{name} must be [B,3,H,W]; got {tuple(x.shape)}")
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def forward(self, left_input, right_input):
+        if self.device is None:
+            raise RuntimeError("no HIP device is available and lwsnet_amd has no CPU fallback")
+        if self._params is None:
+            raise RuntimeError("set_state_dict() must be called before forward()")
+        left = self._input(left_input, "left_input")
+        right = self._input(right_input, "right_input")
+        if left.shape != right.shape:
+            raise ValueError(f"left/right shapes differ: {tuple(left.shape)} vs {tuple(right.shape)}")
+        B, _, H, W = left.shape
+        check_size(H, W, self.maxdisplist[0])
+        with torch.no_grad(), torch.cuda.device(self.device):
+            both = submodules.feature_extraction(torch.cat([left, right], 0), self._params)   # models.py:110-111
+            feats_l = [f[:B].contiguous() for f in both]
+            feats_r = [f[B:].contiguous() for f in both]
+            pred = ops.disparity_stages(self._h, feats_l, feats_r, H, W)                     # :115-156
+            pred.append(submodules.refine(left, pred[2], self._params))                       # :158-162
+        return pred
+
+    __call__ = forward

@@ -1,0 +1,120 @@
+"""Per-op wrappers over the C ABI for torch ROCm tensors (device memory + stream plumbing only).
+
+Each function mirrors one reference symbol (see include/lwsnet_hip.h for file:line) and
+launches the hand-written HIP kernel on torch's current stream.  No CPU path exists:
+tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a torch tensor on a HIP device (the disparity path has no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def volume_l1_shift(feat_l, feat_r, maxdisp):
+    """LWSNet._build_volume_2d (models/models.py:58-76)."""
+    L, R = _dev(feat_l, "feat_l"), _dev(feat_r, "feat_r")
+    if L.shape != R.shape or L.dim() != 4:
+        raise ValueError(f"feat_l/feat_r must both be [B,C,h,w]; got {tuple(L.shape)} and {tuple(R.shape)}")
+    B, C, h, w = L.shape
+    cost = torch.empty((B, maxdisp, h, w), device=L.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(L.device):
+        _lib.check(lib.lws_volume_l1_shift(_ptr(L), _ptr(R), _ptr(cost), B, C, h, w, int(maxdisp), _stream()),
+                   "lws_volume_l1_shift")
+    return cost
+
+
+def volume_l1_warp(feat_l, feat_r, prev_disp, maxdisp, return_wflow=False):
+    """forward() glue (models/models.py:119-121) + _build_volume_2d3 (:78-104) + warp (:28-55)."""
+    L, R, P = _dev(feat_l, "feat_l"), _dev(feat_r, "feat_r"), _dev(prev_disp, "prev_disp")
+    if L.shape != R.shape or L.dim() != 4:
+        raise ValueError(f"feat_l/feat_r must both be [B,C,h,w]; got {tuple(L.shape)} and {tuple(R.shape)}")
+    B, C, h, w = L.shape
+    if P.dim() != 4 or P.shape[0] != B or P.shape[1] != 1:
+        raise ValueError(f"prev_disp must be [B,1,H,W]; got {tuple(P.shape)}")
+    H, W = P.shape[2], P.shape[3]
+    cost = torch.empty((B, 2 * maxdisp - 1, h, w), device=L.device, dtype=torch.float32)
+    wflow = torch.empty((B, h, w), device=L.device, dtype=torch.float32) if return_wflow else None
+    lib = _lib.load()
+    with torch.cuda.device(L.device):
+        _lib.check(lib.lws_volume_l1_warp(_ptr(L), _ptr(R), _ptr(P), _ptr(cost), _ptr(wflow), B, C, h, w, H, W,
+                                          int(maxdisp), _stream()), "lws_volume_l1_warp")
+    return (cost, wflow) if return_wflow else cost
+
+
+def conv3d_stack(handle, stage, cost):
+    """volume_postprocess[stage](cost) + cost (models/models.py:136-138)."""
+    c = _dev(cost, "cost")
+    if c.dim() != 4:
+        raise ValueError(f"cost must be [B,D,h,w]; got {tuple(c.shape)}")
+    B, D, h, w = c.shape
+    out = torch.empty_like(c)
+    lib = _lib.load()
+    with torch.cuda.device(c.device):
+        _lib.check(lib.lws_conv3d_stack(handle, int(stage), _ptr(c), _ptr(out), B, D, h, w, _stream()),
+                   "lws_conv3d_stack")
+    return out
+
+
+def softargmin(cost, start):
+    """F.softmax(-cost, 1) + disparity_regression (models/models.py:142,151-152,167-179)."""
+    c = _dev(cost, "cost")
+    B, D, h, w = c.shape
+    low = torch.empty((B, h, w), device=c.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(c.device):
+        _lib.check(lib.lws_softargmin(_ptr(c), _ptr(low), B, D, h, w, float(start), _stream()), "lws_softargmin")
+    return low
+
+
+def upsample_add(disp_low, prev, H, W):
+    """models/models.py:145-148,153-156."""
+    low = _dev(disp_low, "disp_low")
+    B, h, w = low.shape
+    prev = _dev(prev, "prev") if prev is not None else None
+    out = torch.empty((B, 1, H, W), device=low.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(low.device):
+        _lib.check(lib.lws_upsample_add(_ptr(low), _ptr(prev), _ptr(out), B, h, w, int(H), int(W), _stream()),
+                   "lws_upsample_add")
+    return out
+
+
+def disparity_stages(handle, feats_l, feats_r, H, W):
+    """The body of `for scale in range(3)` (models/models.py:115-156): returns [pred1, pred2, pred3]."""
+    fl = [_dev(t, f"feats_l[{i}]") for i, t in enumerate(feats_l)]
+    fr = [_dev(t, f"feats_r[{i}]") for i, t in enumerate(feats_r)]
+    if len(fl) != 3 or len(fr) != 3:
+        raise ValueError("feats_l / feats_r must hold the three feature maps (1/8, 1/4, 1/2)")
+    B = fl[0].shape[0]
+    want = [(B, 16, H // 8, W // 8), (B, 16, H // 4, W // 4), (B, 8, H // 2, W // 2)]
+    for i in range(3):
+        if tuple(fl[i].shape) != want[i] or tuple(fr[i].shape) != want[i]:
+            raise ValueError(f"stage {i + 1} features must be {want[i]}; got {tuple(fl[i].shape)} / {tuple(fr[i].shape)}")
+    preds = [torch.empty((B, 1, H, W), device=fl[0].device, dtype=torch.float32) for _ in range(3)]
+    arr = ctypes.c_void_p * 3
+    lib = _lib.load()
+    with torch.cuda.device(fl[0].device):
+        _lib.check(lib.lws_disparity_stages(handle, arr(*[t.data_ptr() for t in fl]), arr(*[t.data_ptr() for t in fr]),
+                                            B, int(H), int(W), arr(*[t.data_ptr() for t in preds]), _stream()),
+                   "lws_disparity_stages")
+    return preds

@@ -48,7 +48,7 @@ def _box_blur(a, k=9):
 def gt_disparity(H, W):
     y = np.arange(H, dtype=np.float64)[:, None]
     x = np.arange(W, dtype=np.float64)[None, :]
-    return 4.0 + 60.0 * y / H + 6.0 * np.sin(2.0 * np.pi * x / W * 3.0)
+    return 10.0 + 60.0 * y / H + 6.0 * np.sin(2.0 * np.pi * x / W * 3.0)
 
 
 def _normalise(img01):

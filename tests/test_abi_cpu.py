@@ -1,0 +1,97 @@
+"""The C-ABI library builds for gfx950, loads without a GPU and exports every symbol
+include/lwsnet_hip.h declares; host-side argument / state errors behave like the
+reference's Python exceptions (ValueError for bad shapes, RuntimeError otherwise)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from lwsnet_amd import _lib
+from lwsnet_amd.weights import default_args, make_state_dict
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "lwsnet_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lws_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_prototypes_agree():
+    assert _declared() == sorted(_lib.PROTOTYPES)
+
+
+def test_library_exports_every_symbol(hip_lib):
+    for name in _declared():
+        assert hasattr(hip_lib, name), name
+    assert hip_lib.lws_abi_version() == 1
+
+
+def _create(lib, **kw):
+    a = default_args(**kw)
+    cfg = _lib.LwsConfig((ctypes.c_int32 * 3)(*a.maxdisplist), a.layers_3d, a.channels_3d,
+                         (ctypes.c_int32 * 3)(*a.growth_rate))
+    h = ctypes.c_void_p()
+    rc = lib.lws_create(ctypes.byref(cfg), ctypes.byref(h))
+    return rc, h
+
+
+def test_create_rejects_unsupported_config(hip_lib):
+    rc, _ = _create(hip_lib, channels_3d=5)
+    assert rc == _lib.LWS_ERR_INVALID
+    with pytest.raises(ValueError, match="not supported"):
+        _lib.check(rc)
+    rc, _ = _create(hip_lib, maxdisplist=(100, 5, 5))
+    assert rc == _lib.LWS_ERR_INVALID
+
+
+def test_set_tensor_validates_keys_and_shapes(hip_lib):
+    rc, h = _create(hip_lib)
+    assert rc == 0
+    sd = make_state_dict(7)
+    k = "volume_postprocess.0.1.2.weight"
+    v = sd[k]
+    shp = (ctypes.c_int64 * v.ndim)(*v.shape)
+    assert hip_lib.lws_set_tensor(h, k.encode(), v.ctypes.data_as(_lib.c_float_p), shp, v.ndim) == 0
+    assert hip_lib.lws_set_tensor(h, b"no.such.key", v.ctypes.data_as(_lib.c_float_p), shp, v.ndim) == _lib.LWS_ERR_INVALID
+    assert b"unexpected key" in hip_lib.lws_last_error()
+    bad = (ctypes.c_int64 * 2)(3, 3)
+    assert hip_lib.lws_set_tensor(h, k.encode(), v.ctypes.data_as(_lib.c_float_p), bad, 2) == _lib.LWS_ERR_INVALID
+    assert b"shape mismatch" in hip_lib.lws_last_error()
+    # finalize without the full state dict is a state error, not a crash
+    assert hip_lib.lws_finalize(h) == _lib.LWS_ERR_STATE
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.LWS_ERR_STATE, "lws_finalize")
+    assert hip_lib.lws_destroy(h) == 0
+
+
+def test_model_shim_validates_on_host(hip_lib):
+    from lwsnet_amd.models import LWSNet
+    m = LWSNet(default_args(), device=None) if False else None   # constructed below without a device
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("host-only behaviour")
+    m = LWSNet(default_args())
+    assert m.eval() is m
+    with pytest.raises(NotImplementedError):
+        m.train()
+    with pytest.raises(KeyError):
+        m.set_state_dict({"feature_extraction.dres0.0.0.weight": np.zeros((4, 3, 3, 3), np.float32)})
+    sd = make_state_dict(7)
+    sd["StructuredToParameterName@@"] = {}
+    m.set_state_dict(sd)                      # host-side ingest works without a GPU
+    assert len(m.state_dict()) == 226
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(np.zeros((1, 3, 64, 256), np.float32), np.zeros((1, 3, 64, 256), np.float32))
+
+
+def test_check_size_matches_reference_constraints():
+    from lwsnet_amd.synth import check_size
+    check_size(256, 512)
+    check_size(368, 1232)
+    check_size(544, 960, 32)
+    for H, W in ((375, 1242), (540, 960), (256, 128)):
+        with pytest.raises(ValueError):
+            check_size(H, W)
