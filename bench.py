@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo pairs/s through LWSNet.forward at 256x512, maxdisplist=[24,5,5] (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one forward over this rank's batch of synthetic pairs (inputs and weights resident in HBM),
+returning the stage-4 disparity; for N > 1 every rank runs its own pairs (weak scaling, no data-path
+collective) and the stage-4 maps are gathered on rank 0 with ONE RCCL gather per step.
+Rank 0 prints one JSON line.  `roofline` describes the dominant kernel (stage-1 Conv3D 32->32 on fp32
+MFMA): algorithmic FLOPs per launch / average launch duration from hipEvents recorded by the library on
+the launch stream inside the timed region.  `cpu_baseline` is the literal oracle (torch-CPU ops) timed on
+the host cores of the same box, N = 1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+H, W = 256, 512
+PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step (BASELINE config 2: 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from lwsnet_amd import _lib, dist as ldist
+    from lwsnet_amd.models import LWSNet
+    from lwsnet_amd.synth import make_batch
+    from lwsnet_amd.weights import default_args, make_state_dict
+
+    rank, local_rank, world = ldist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the measured path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+
+    margs = default_args()
+    sd = make_state_dict(7)
+    model = LWSNet(margs, device=dev).set_state_dict(sd).eval()
+    B = args.batch
+    left_np, right_np = make_batch(B, H, W, first_index=rank * B)
+    left, right = torch.from_numpy(left_np).to(dev), torch.from_numpy(right_np).to(dev)
+    lib = _lib.load()
+    _lib.check(lib.lws_reserve(model._h, B, H, W), "lws_reserve")
+
+    gathered = [torch.empty((B, 1, H, W), device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        pred = model(left, right)
+        if world > 1:
+            dist.gather(pred[3], gathered, dst=0)
+        return pred
+
+    for _ in range(args.warmup):
+        step()
+    _lib.check(lib.lws_profile_enable(model._h, 1), "lws_profile_enable")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pred = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tot = (ctypes.c_double * _lib.LWS_KC_COUNT)()
+    cnt = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
+    _lib.check(lib.lws_profile_read(model._h, tot, cnt), "lws_profile_read")
+    _lib.check(lib.lws_profile_enable(model._h, 0), "lws_profile_enable")
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernels = {}
+    for kc in range(_lib.LWS_KC_COUNT):
+        if cnt[kc]:
+            kernels[lib.lws_kernel_class_name(kc).decode()] = {"launches_per_step": cnt[kc] / args.steps,
+                                                               "avg_us": 1e3 * tot[kc] / cnt[kc]}
+    hot_ms = sum(tot) / args.steps
+
+    # dominant kernel: stage-1 Conv3D c3 -> c3 (k_conv3d_mid16): 2*27*c3*c3 FLOP per voxel, voxels = B*D1*(H/8)*(W/8)
+    c3 = margs.channels_3d * margs.growth_rate[0]
+    vox = B * margs.maxdisplist[0] * (H // 8) * (W // 8)
+    flop_per_launch = 2.0 * 27 * c3 * c3 * vox
+    mid = kernels.get("conv3d_mid16")
+    roof = None
+    if mid:
+        achieved = flop_per_launch / (mid["avg_us"] * 1e-6) / 1e12
+        roof = {"bound": "mfma", "kernel": "k_conv3d_mid16<32,3,4>", "achieved": round(achieved, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None, "flop_per_launch": flop_per_launch, "avg_launch_us": round(mid["avg_us"], 2)}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import lws_oracle                      # checker only: the CPU leg of the report
+        torch.set_num_threads(os.cpu_count() or 1)
+        l1, r1 = left_np[:1], right_np[:1]
+        lws_oracle.forward(l1, r1, sd)                     # warm-up
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            ref = lws_oracle.forward(l1, r1, sd)
+            ts.append(time.perf_counter() - t1)
+        med = sorted(ts)[1]
+        err = [float((pred[s][:1].cpu() - ref[s]).abs().max()) for s in range(4)]
+        cpu = {"value": round(1.0 / med, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"3 forwards of 1 pair {H}x{W} after 1 warm-up, median; literal oracle on torch-CPU "
+                         f"{torch.__version__} (Paddle-CPU stand-in)",
+               "max_abs_vs_gpu_per_stage": [round(e, 6) for e in err]}
+
+    pairs = world * B * args.steps
+    out = {
+        "metric": "stereo pairs/sec @256x512 maxdisp=192 (stage-4)",
+        "value": round(pairs / elapsed, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 2: batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[24,5,5], all 4 stages",
+                   "pairs_per_gpu": B, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4" if world > 1 else "single GPU",
+                   "weights": "seeded synthetic (seed 7, calibrated BN)"},
+        "roofline": roof, "cpu_baseline": cpu,
+        "hot_path_ms_per_step": round(hot_ms, 4), "kernels": {k: {a: round(b, 2) for a, b in v.items()} for k, v in kernels.items()},
+    }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -103,6 +103,29 @@ int lws_upsample_add(const float *disp_low, const float *prev, float *out,
 int lws_disparity_stages(lws_handle h, const float *const featsL[3], const float *const featsR[3],
                          int B, int H, int W, float *const pred_out[3], void *stream);
 
+/* ---- measurement hooks (bench.py) ------------------------------------------------------ */
+/* Kernel classes timed by the built-in profiler. */
+typedef enum {
+    LWS_KC_VOLUME_SHIFT = 0,   /* k_volume_l1_shift                      */
+    LWS_KC_VOLUME_WARP = 1,    /* k_volume_l1_warp                       */
+    LWS_KC_CONV3D_FIRST = 2,   /* k_conv3d_first  (1 -> C3)              */
+    LWS_KC_CONV3D_MID16 = 3,   /* k_conv3d_mid16  (C3 -> C3, C3 % 16 == 0, fp32 MFMA) */
+    LWS_KC_CONV3D_MID8 = 4,    /* k_conv3d_mid8   (8 -> 8, fp32 MFMA)    */
+    LWS_KC_CONV3D_LAST = 5,    /* k_conv3d_last   (C3 -> 1, + skip)      */
+    LWS_KC_SOFTARGMIN = 6,     /* k_softargmin                           */
+    LWS_KC_UPSAMPLE = 7,       /* k_upsample_add                         */
+    LWS_KC_COUNT = 8
+} lws_kernel_class;
+
+/* on != 0: every kernel the handle launches from now on is bracketed by a hipEvent pair recorded on
+ * the launch stream (records are dropped, never blocking, beyond 65536 launches).  on == 0: stop.
+ * Either way the accumulated records are cleared. */
+int lws_profile_enable(lws_handle h, int on);
+/* Synchronises the recorded events and returns, per kernel class, the summed device time in
+ * milliseconds and the number of launches.  Both arrays have LWS_KC_COUNT entries. */
+int lws_profile_read(lws_handle h, double *total_ms, int64_t *launches);
+const char *lws_kernel_class_name(int kernel_class);
+
 #ifdef __cplusplus
 }
 #endif

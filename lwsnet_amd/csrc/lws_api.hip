@@ -147,18 +147,71 @@ static int check_size(const lws_ctx *h, int B, int H, int W)
     return LWS_OK;
 }
 
+// ---- built-in profiler: one hipEvent pair per launch on the launch stream ---------------------
+static const size_t kMaxProfRecords = 65536;
+
+static hipEvent_t prof_event(lws_ctx *h)
+{
+    if (!h->evt_pool.empty()) {
+        hipEvent_t e = h->evt_pool.back();
+        h->evt_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct ProfScope {
+    lws_ctx *h;
+    hipStream_t st;
+    lws_prof_rec rec;
+    bool live;
+    ProfScope(lws_ctx *h_, int kc, hipStream_t st_) : h(h_), st(st_), live(false)
+    {
+        if (!h->prof_on || h->prof.size() >= kMaxProfRecords) return;
+        rec.kc = kc;
+        rec.t0 = prof_event(h);
+        rec.t1 = prof_event(h);
+        if (!rec.t0 || !rec.t1) return;
+        live = hipEventRecord(rec.t0, st) == hipSuccess;
+    }
+    ~ProfScope()
+    {
+        if (!live) return;
+        if (hipEventRecord(rec.t1, st) == hipSuccess) h->prof.push_back(rec);
+    }
+};
+
+static void prof_clear(lws_ctx *h)
+{
+    for (lws_prof_rec &r : h->prof) {
+        h->evt_pool.push_back(r.t0);
+        h->evt_pool.push_back(r.t1);
+    }
+    h->prof.clear();
+}
+
 static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost_out, float *act_a, float *act_b,
                         int B, int D, int hh, int ww, hipStream_t st)
 {
     const Stage3d &s = h->stage[stage];
-    int rc = launch_conv3d_first(s, cost_in, act_a, B, D, hh, ww, st);
+    int rc;
+    {
+        ProfScope p(h, LWS_KC_CONV3D_FIRST, st);
+        rc = launch_conv3d_first(s, cost_in, act_a, B, D, hh, ww, st);
+    }
     if (rc) return rc;
     float *src = act_a, *dst = act_b;
     for (int j = 1; j <= h->cfg.layers_3d; ++j) {
-        rc = launch_conv3d_mid(s, j, src, dst, B, D, hh, ww, st);
+        {
+            ProfScope p(h, s.c3 == 8 ? LWS_KC_CONV3D_MID8 : LWS_KC_CONV3D_MID16, st);
+            rc = launch_conv3d_mid(s, j, src, dst, B, D, hh, ww, st);
+        }
         if (rc) return rc;
         std::swap(src, dst);
     }
+    ProfScope p(h, LWS_KC_CONV3D_LAST, st);
     return launch_conv3d_last(s, src, cost_in, cost_out, B, D, hh, ww, st);
 }
 
@@ -207,9 +260,43 @@ int lws_create(const lws_config *cfg, lws_handle *out)
     return LWS_OK;
 }
 
+int lws_profile_enable(lws_handle h, int on)
+{
+    LWS_CHECK_ARG(h, "lws_profile_enable: null handle");
+    prof_clear(h);
+    h->prof_on = on != 0;
+    return LWS_OK;
+}
+
+int lws_profile_read(lws_handle h, double *total_ms, int64_t *launches)
+{
+    LWS_CHECK_ARG(h && total_ms && launches, "lws_profile_read: null argument");
+    for (int i = 0; i < LWS_KC_COUNT; ++i) {
+        total_ms[i] = 0.0;
+        launches[i] = 0;
+    }
+    for (lws_prof_rec &r : h->prof) {
+        LWS_HIP(hipEventSynchronize(r.t1));
+        float ms = 0.f;
+        LWS_HIP(hipEventElapsedTime(&ms, r.t0, r.t1));
+        total_ms[r.kc] += ms;
+        launches[r.kc] += 1;
+    }
+    return LWS_OK;
+}
+
+const char *lws_kernel_class_name(int kc)
+{
+    static const char *names[LWS_KC_COUNT] = {"volume_l1_shift", "volume_l1_warp", "conv3d_first", "conv3d_mid16",
+                                              "conv3d_mid8",     "conv3d_last",    "softargmin",   "upsample_add"};
+    return kc >= 0 && kc < LWS_KC_COUNT ? names[kc] : "?";
+}
+
 int lws_destroy(lws_handle h)
 {
     if (!h) return LWS_OK;
+    prof_clear(h);
+    for (hipEvent_t e : h->evt_pool) (void)hipEventDestroy(e);
     if (h->params) (void)hipFree(h->params);
     if (h->ws) (void)hipFree(h->ws);
     delete h;
@@ -386,18 +473,27 @@ int lws_disparity_stages(lws_handle h, const float *const featsL[3], const float
     for (int s = 0; s < 3; ++s) {
         int D, hh, ww;
         stage_dims(h, s, H, W, D, hh, ww);
-        if (s == 0)
+        if (s == 0) {
+            ProfScope p(h, LWS_KC_VOLUME_SHIFT, st);
             rc = launch_volume_l1_shift(featsL[0], featsR[0], raw, B, feat_c[0], hh, ww, D, st);            // :131
-        else
+        } else {
+            ProfScope p(h, LWS_KC_VOLUME_WARP, st);
             rc = launch_volume_l1_warp(featsL[s], featsR[s], pred_out[s - 1], raw, nullptr, B, feat_c[s], hh, ww, H, W,
                                        h->cfg.maxdisplist[s], st);                                           // :119-127
+        }
         if (rc) return rc;
         rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st);                                  // :136-138
         if (rc) return rc;
         const float start = s == 0 ? 0.0f : (float)(-h->cfg.maxdisplist[s] + 1);
-        rc = launch_softargmin(cost, low, B, D, hh, ww, start, st);                                          // :142,151
+        {
+            ProfScope p(h, LWS_KC_SOFTARGMIN, st);
+            rc = launch_softargmin(cost, low, B, D, hh, ww, start, st);                                      // :142,151
+        }
         if (rc) return rc;
-        rc = launch_upsample_add(low, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], B, hh, ww, H, W, st); // :145-156
+        {
+            ProfScope p(h, LWS_KC_UPSAMPLE, st);
+            rc = launch_upsample_add(low, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], B, hh, ww, H, W, st);   // :145-156
+        }
         if (rc) return rc;
     }
     return LWS_OK;

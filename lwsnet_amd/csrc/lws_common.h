@@ -50,8 +50,16 @@ struct Stage3d {
 
 }  // namespace lws
 
+struct lws_prof_rec {
+    int kc;
+    hipEvent_t t0, t1;
+};
+
 struct lws_ctx {
     lws_config cfg;
+    bool prof_on = false;
+    std::vector<lws_prof_rec> prof;          // records of the current session
+    std::vector<hipEvent_t> evt_pool;        // events available for reuse
     int device = 0;
     bool finalized = false;
     std::map<std::string, std::vector<float>> host;        // state dict as given

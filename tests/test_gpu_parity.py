@@ -1,0 +1,207 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP kernels, called through the C ABI,
+against the deterministic C oracle (bit for bit: same float32 operations in the same order) and
+against the literal oracle / committed golden vectors (within the stated float32 tolerances)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from lwsnet_amd.synth import make_batch
+from lwsnet_amd.weights import default_args, make_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev, hip_lib):
+    from lwsnet_amd.models import LWSNet
+    m = LWSNet(default_args(), device=dev)
+    m.set_state_dict(make_state_dict(7))
+    return m.eval()
+
+
+def cu(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def assert_bits(got, want, what):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
+    bad = int((got != want).sum())
+    assert bad == 0, f"{what}: {bad}/{want.size} elements differ, max abs {np.abs(got - want).max():.3e}"
+
+
+# ------------------------------------------------------------------ K1
+@pytest.mark.parametrize("shape,D", [((1, 16, 8, 32), 24), ((2, 16, 46, 154), 24), ((1, 16, 32, 64), 24),
+                                     ((1, 16, 68, 120), 32), ((3, 16, 5, 24), 24)])
+def test_volume_shift_bitexact(dev, hip_lib, shape, D):
+    from lwsnet_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.default_rng(11)
+    L = rng.standard_normal(shape).astype(np.float32)
+    R = rng.standard_normal(shape).astype(np.float32)
+    assert_bits(ops.volume_l1_shift(cu(L, dev), cu(R, dev), D), C.volume_l1_shift(L, R, D), "volume_l1_shift")
+
+
+def test_volume_shift_golden(dev, hip_lib):
+    from lwsnet_amd import ops
+    g = golden("volume_shift.npz")
+    c = ops.volume_l1_shift(cu(g["L"], dev), cu(g["R"], dev), int(g["D"])).cpu().numpy()
+    np.testing.assert_allclose(c, g["cost"], rtol=0, atol=2e-5)
+
+
+def test_volume_shift_rejects_narrow_input(dev, hip_lib):
+    from lwsnet_amd import ops
+    x = torch.zeros((1, 16, 4, 16), device=dev)
+    with pytest.raises(ValueError):            # models.py:72 needs w > d for every hypothesis
+        ops.volume_l1_shift(x, x, 24)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.volume_l1_shift(x.cpu(), x.cpu(), 8)
+
+
+# ------------------------------------------------------------------ K2
+def _warp_case(rng, B, C, h, w, scale):
+    H, W = h * scale, w * scale
+    L = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    R = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    ramp = 0.35 * W - 0.5 * W * np.arange(W, dtype=np.float64)[None, None, None, :] / W
+    prev = (ramp + rng.random((B, 1, H, W)) * 6.0).astype(np.float32)
+    return L, R, prev, H, W
+
+
+@pytest.mark.parametrize("B,C,h,w,scale,m", [(1, 16, 16, 64, 4, 5), (2, 16, 46, 78, 4, 5), (1, 8, 64, 128, 2, 5),
+                                             (2, 8, 34, 50, 2, 3)])
+def test_volume_warp_bitexact(dev, hip_lib, B, C, h, w, scale, m):
+    from lwsnet_amd import ops
+    from oracle import c_oracle as C_
+    L, R, prev, H, W = _warp_case(np.random.default_rng(5), B, C, h, w, scale)
+    cost, wflow = ops.volume_l1_warp(cu(L, dev), cu(R, dev), cu(prev, dev), m, return_wflow=True)
+    wf = C_.resize_bilinear(prev[:, 0], h, w, float(h), float(np.float32(1) / np.float32(H)))
+    assert_bits(wflow, wf, "wflow")
+    assert_bits(cost, C_.volume_l1_warp(L, R, wf, m), "volume_l1_warp")
+
+
+def test_volume_warp_golden(dev, hip_lib):
+    from lwsnet_amd import ops
+    g = golden("volume_warp.npz")
+    cost, wflow = ops.volume_l1_warp(cu(g["L"], dev), cu(g["R"], dev), cu(g["prev"], dev), int(g["m"]), True)
+    np.testing.assert_allclose(wflow.cpu().numpy(), g["wflow"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(cost.cpu().numpy(), g["cost"], rtol=0, atol=3e-4)   # 1-ulp flow differences, see CPU test
+
+
+# ------------------------------------------------------------------ K3
+@pytest.mark.parametrize("stage,shape", [(0, (1, 24, 8, 32)), (0, (2, 24, 10, 40)), (0, (1, 24, 32, 64)),
+                                         (0, (1, 32, 9, 48)), (1, (1, 9, 8, 16)), (1, (2, 9, 30, 70)),
+                                         (2, (1, 9, 64, 128)), (2, (1, 5, 7, 33))])
+def test_conv3d_stack_bitexact(dev, model, stage, shape):
+    from lwsnet_amd import ops
+    from oracle import c_oracle as C
+    c = (np.random.default_rng(stage + 1).random(shape) * 12.0).astype(np.float32)
+    got = ops.conv3d_stack(model._h, stage, cu(c, dev))
+    assert_bits(got, C.conv3d_stack(c, model.state_dict(), stage), f"conv3d_stack stage {stage} {shape}")
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_conv3d_stack_golden(dev, model, stage):
+    from lwsnet_amd import ops
+    g = golden(f"conv3d_stage{stage}.npz")
+    y = ops.conv3d_stack(model._h, stage, cu(g["cost_in"], dev)).cpu().numpy()
+    scale = np.abs(g["cost_out"]).max()
+    assert np.abs(y - g["cost_out"]).max() < 2e-6 * scale + 1e-5
+
+
+# ------------------------------------------------------------------ K4 / K5
+@pytest.mark.parametrize("name", ["softargmin_d24", "softargmin_d9"])
+def test_softargmin_upsample(dev, hip_lib, name):
+    from lwsnet_amd import ops
+    from oracle import c_oracle as C
+    g = golden(name + ".npz")
+    low = ops.softargmin(cu(g["cost"], dev), float(g["start"]))
+    want_low = C.softargmin(g["cost"], float(g["start"]))
+    assert_bits(low, want_low, "softargmin")
+    np.testing.assert_allclose(low.cpu().numpy(), g["low"], rtol=0, atol=5e-6)
+    H, W = g["prev"].shape[2:]
+    up = ops.upsample_add(low, cu(g["prev"], dev), H, W)
+    assert_bits(up, C.upsample_add(want_low, g["prev"], H, W), "upsample_add")
+    np.testing.assert_allclose(up.cpu().numpy(), g["up"], rtol=0, atol=1e-4)
+    up0 = ops.upsample_add(low, None, H, W)
+    assert_bits(up0, C.upsample_add(want_low, None, H, W), "upsample (no prev)")
+
+
+def test_softargmin_extreme_costs(dev, hip_lib):
+    from lwsnet_amd import ops
+    from oracle import c_oracle as C
+    c = np.zeros((1, 24, 2, 64), np.float32)
+    c[0, :, 0, :] = np.linspace(0, 300, 24, dtype=np.float32)[:, None]      # exp underflow on all but one
+    c[0, :, 1, :] = 1e4
+    c[0, 7, 1, :] = -1e4                                                       # one-hot
+    low = ops.softargmin(cu(c, dev), 0.0)
+    assert_bits(low, C.softargmin(c, 0.0), "softargmin extremes")
+    assert float(low[0, 1, 0]) == 7.0
+
+
+# ------------------------------------------------------------------ whole path
+def test_disparity_stages_bitexact_vs_c_oracle(dev, model):
+    """All three stages chained through the C ABI equal the C oracle bit for bit."""
+    from lwsnet_amd import ops
+    from oracle import c_oracle as C
+    g = golden("e2e_64x256.npz")
+    fl = [g[f"featL{i}"] for i in range(3)]
+    fr = [g[f"featR{i}"] for i in range(3)]
+    got = ops.disparity_stages(model._h, [cu(f, dev) for f in fl], [cu(f, dev) for f in fr], 64, 256)
+    want = C.disparity_stages(fl, fr, 64, 256, model.state_dict())
+    for s in range(3):
+        assert_bits(got[s], want[s], f"stage {s + 1}")
+    # and against the literal oracle's golden output: stage 1 inside the 1e-3 px target; stages 2/3
+    # carry the amplified sub-ulp flow differences every fp32 implementation shows (CPU test of the same name)
+    err = [float(np.abs(got[s].cpu().numpy() - g[f"pred{s}"]).max()) for s in range(3)]
+    assert err[0] < 1e-3 and err[1] < 5e-3 and err[2] < 1e-2, err
+
+
+def test_forward_matches_literal_oracle(dev, model):
+    """LWSNet.forward end to end (2D networks through PyTorch-ROCm plumbing) vs the golden stage maps."""
+    g = golden("e2e_64x256.npz")
+    pred = model(g["left"], g["right"])
+    assert len(pred) == 4 and all(tuple(p.shape) == (1, 1, 64, 256) and p.dtype == torch.float32 for p in pred)
+    err = [float(np.abs(pred[s].cpu().numpy() - g[f"pred{s}"]).max()) for s in range(4)]
+    print("max-abs vs literal oracle per stage:", err)
+    assert err[0] < 1e-3, err                       # north_star tolerance at the stage the noise has not amplified
+    assert max(err) < 2e-2, err                     # fp32 noise floor of stages 2-4 (numerics)
+    from oracle.lws_oracle import error_3px
+    assert error_3px(pred[3].cpu().numpy(), np.maximum(g["pred3"], 1e-3)) == 0.0
+
+
+def test_hot_path_full_size_properties(dev, model):
+    """BASELINE config 2/4 sizes: size-independent properties instead of a slow CPU oracle run."""
+    from lwsnet_amd import ops, submodules
+    left, right = make_batch(2, 256, 512, 0)
+    with torch.no_grad():
+        both = submodules.feature_extraction(cu(np.concatenate([left, right]), dev), model._params)
+    fl = [f[:2].contiguous() for f in both]
+    fr = [f[2:].contiguous() for f in both]
+    p2 = ops.disparity_stages(model._h, fl, fr, 256, 512)
+    for b in range(2):                               # batch sharding is pure partitioning: bitwise equal
+        p1 = ops.disparity_stages(model._h, [f[b:b + 1].contiguous() for f in fl], [f[b:b + 1].contiguous() for f in fr], 256, 512)
+        for s in range(3):
+            assert torch.equal(p2[s][b:b + 1], p1[s]), (b, s)
+    again = ops.disparity_stages(model._h, fl, fr, 256, 512)
+    assert all(torch.equal(a, b) for a, b in zip(p2, again))             # deterministic
+    assert all(torch.isfinite(p).all() for p in p2)
+    # identical left/right features: the stage-1 volume has zero cost at d = 0 and the path stays finite
+    same = ops.disparity_stages(model._h, fl, fl, 256, 512)
+    assert all(torch.isfinite(p).all() for p in same)
+    full = model(left, right)
+    assert len(full) == 4 and all(tuple(p.shape) == (2, 1, 256, 512) and torch.isfinite(p).all() for p in full)
+
+
+def test_forward_rejects_bad_sizes(dev, model):
+    z = np.zeros((1, 3, 375, 1242), np.float32)
+    with pytest.raises(ValueError):
+        model(z, z)
+    with pytest.raises(ValueError):
+        model(np.zeros((1, 3, 64, 128), np.float32), np.zeros((1, 3, 64, 128), np.float32))   # W/8 < 24
