@@ -103,6 +103,21 @@ int lws_upsample_add(const float *disp_low, const float *prev, float *out,
 int lws_disparity_stages(lws_handle h, const float *const featsL[3], const float *const featsR[3],
                          int B, int H, int W, float *const pred_out[3], void *stream);
 
+/* ---- the 2D networks around the path ---------- */
+/* feature_extraction, models/submodules.py:113-188 (+ hourglass :35-109): img [N,3,H,W] ->
+ * f8 [N,16,H/8,W/8], f4 [N,16,H/4,W/4], f2 [N,8,H/2,W/2]. */
+int lws_feature_extraction(lws_handle h, const float *img, int N, int H, int W, float *f8, float *f4, float *f2,
+                           void *stream);
+
+/* models/models.py:158-162 with refinement1/refinement2, models/submodules.py:223-327:
+ * pred4 = pred3 + refinement2(concat(refinement1_left(left), refinement1_disp(pred3))).
+ * left [B,3,H,W]; pred3, pred4 [B,1,H,W]. */
+int lws_refine(lws_handle h, const float *left, const float *pred3, int B, int H, int W, float *pred4, void *stream);
+
+/* LWSNet.forward, models/models.py:106-164: left, right [B,3,H,W] -> pred_out[0..3] [B,1,H,W]. */
+int lws_forward(lws_handle h, const float *left, const float *right, int B, int H, int W, float *const pred_out[4],
+                void *stream);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------ */
 /* Kernel classes timed by the built-in profiler. */
 typedef enum {
@@ -114,7 +129,12 @@ typedef enum {
     LWS_KC_CONV3D_LAST = 5,    /* k_conv3d_last   (C3 -> 1, + skip)      */
     LWS_KC_SOFTARGMIN = 6,     /* k_softargmin                           */
     LWS_KC_UPSAMPLE = 7,       /* k_upsample_add                         */
-    LWS_KC_COUNT = 8
+    LWS_KC_FEATURE2D = 8,      /* k_conv2d_nchw (feature extractor)      */
+    LWS_KC_REF_FIRST = 9,      /* k_ref_first                            */
+    LWS_KC_REF_DWS = 10,       /* k_ref_dws                              */
+    LWS_KC_REF_CONV64 = 11,    /* k_ref_conv64                           */
+    LWS_KC_REF_LAST = 12,      /* k_ref_last                             */
+    LWS_KC_COUNT = 13
 } lws_kernel_class;
 
 /* on != 0: every kernel the handle launches from now on is bracketed by a hipEvent pair recorded on

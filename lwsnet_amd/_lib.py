@@ -38,11 +38,14 @@ PROTOTYPES = {
     "lws_softargmin": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "lws_upsample_add": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lws_disparity_stages": (_i, [_vp, _vp * 3, _vp * 3, _i, _i, _i, _vp * 3, _vp]),
+    "lws_feature_extraction": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "lws_refine": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "lws_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp * 4, _vp]),
     "lws_profile_enable": (_i, [_vp, _i]),
     "lws_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), c_int64_p]),
     "lws_kernel_class_name": (ctypes.c_char_p, [_i]),
 }
-LWS_KC_COUNT = 8
+LWS_KC_COUNT = 13
 
 _lib = None
 

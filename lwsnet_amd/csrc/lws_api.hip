@@ -91,7 +91,11 @@ static void fold_bn(const lws_ctx *h, const std::string &p, std::vector<float> &
 }
 
 struct WsLayout {
-    size_t act_a, act_b, cost_raw, cost_out, low, total;   // float offsets
+    size_t act_a, act_b, cost_raw, cost_out, low, total;   // float offsets (hot path)
+    // 2D networks: feature-extractor maps for N = 2B images, refinement ping-pong maps
+    size_t fe_a0, fe_o, fe_a2, fe_o2, fe_c1, fe_pre, fe_c3, fe_f8, fe_f4, fe_o3, fe_cls, fe_f2;
+    size_t r_a, r_b, r_c;
+    size_t total_all;
 };
 
 static bool stage_dims(const lws_ctx *h, int s, int H, int W, int &D, int &hh, int &ww)
@@ -121,6 +125,26 @@ static WsLayout ws_layout(const lws_ctx *h, int B, int H, int W)
     L.cost_out = L.cost_raw + al(max_cost);
     L.low = L.cost_out + al(max_cost);
     L.total = L.low + al((size_t)B * (H / 2) * (W / 2));
+    const size_t N = 2 * (size_t)B, p2 = (size_t)(H / 2) * (W / 2), p4 = (size_t)(H / 4) * (W / 4),
+                 p8 = (size_t)(H / 8) * (W / 8);
+    size_t o = L.total;
+    auto take = [&](size_t n) { size_t r = o; o += al(n); return r; };
+    L.fe_a0 = take(N * 4 * p2);
+    L.fe_o = take(N * 8 * p2);
+    L.fe_a2 = take(N * 4 * p2);
+    L.fe_o2 = take(N * 8 * p2);
+    L.fe_c1 = take(N * 16 * p4);
+    L.fe_pre = take(N * 16 * p4);
+    L.fe_c3 = take(N * 16 * p8);
+    L.fe_f8 = take(N * 16 * p8);
+    L.fe_f4 = take(N * 16 * p4);
+    L.fe_o3 = take(N * 8 * p2);
+    L.fe_cls = take(N * 8 * p2);
+    L.fe_f2 = take(N * 8 * p2);
+    L.r_a = take((size_t)B * H * W * 32);
+    L.r_b = take((size_t)B * H * W * 32);
+    L.r_c = take((size_t)B * H * W * 32);
+    L.total_all = o;
     return L;
 }
 
@@ -215,9 +239,259 @@ static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost
     return launch_conv3d_last(s, src, cost_in, cost_out, B, D, hh, ww, st);
 }
 
+
+// ---- 2D networks: parameter slab entries and execution ---------------------------------------
+struct SlabBuilder {
+    std::vector<float> &slab;
+    explicit SlabBuilder(std::vector<float> &s) : slab(s) {}
+    size_t put(const std::vector<float> &v)
+    {
+        slab.resize((slab.size() + 63) & ~(size_t)63, 0.0f);
+        size_t o = slab.size();
+        slab.insert(slab.end(), v.begin(), v.end());
+        return o;
+    }
+};
+
+struct Net2dOffsets {
+    struct L { size_t w, s, t; bool bn; };
+    L fe[12];
+    size_t r1_first[2];
+    struct D { size_t s, t, dw, pw; };
+    D r1[2][4], r2[4];
+    size_t r2f_s, r2f_t, r2f_w, r2_last;
+};
+
+static bool have_all_2d(const lws_ctx *h)
+{
+    for (const auto &kv : h->spec)
+        if (kv.first.compare(0, 19, "volume_postprocess.") != 0 && !h->host.count(kv.first)) return false;
+    return true;
+}
+
+static const struct { const char *name; int cin, cout, stride, pad, dil; bool tr, bn, relu; } kFeLayers[12] = {
+    {"dres0.0", 3, 4, 2, 2, 2, false, true, true},         {"dres0.2", 4, 8, 1, 4, 4, false, true, true},
+    {"dres1.0", 8, 4, 1, 2, 2, false, true, true},         {"dres1.2", 4, 8, 1, 2, 2, false, true, false},
+    {"dres2.conv1.0", 8, 16, 2, 1, 1, false, true, true},  {"dres2.conv2.0", 16, 16, 1, 1, 1, false, true, true},
+    {"dres2.conv3.0", 16, 16, 2, 1, 1, false, true, true}, {"dres2.conv4.0", 16, 16, 1, 1, 1, false, true, true},
+    {"dres2.conv5", 16, 16, 2, 1, 1, true, true, true},    {"dres2.conv6", 16, 8, 2, 1, 1, true, true, false},
+    {"classif1.0", 8, 8, 1, 1, 1, false, true, true},      {"classif1.2", 8, 8, 1, 1, 1, false, false, false}};
+
+static void pack_dws(const lws_ctx *h, SlabBuilder &sb, const std::string &p, Net2dOffsets::D &d)
+{
+    std::vector<float> s, t;
+    fold_bn(h, p + ".0", s, t);
+    d.s = sb.put(s);
+    d.t = sb.put(t);
+    const std::vector<float> &dw = h->host.at(p + ".2.weight");      // [32][1][3][3]
+    std::vector<float> dwt(9 * 32);
+    for (int c = 0; c < 32; ++c)
+        for (int tap = 0; tap < 9; ++tap) dwt[tap * 32 + c] = dw[c * 9 + tap];
+    d.dw = sb.put(dwt);
+    std::vector<float> pw(2 * 2 * 64 * 4);
+    pack_conv2d_mfma(h->host.at(p + ".3.weight").data(), 32, 1, pw.data());   // [32][32][1][1]
+    d.pw = sb.put(pw);
+}
+
+static void build_net2d(const lws_ctx *h, std::vector<float> &slab, Net2dOffsets &o)
+{
+    SlabBuilder sb(slab);
+    const std::string fe = "feature_extraction.";
+    for (int i = 0; i < 12; ++i) {
+        const auto &d = kFeLayers[i];
+        const bool seq = !d.tr && d.bn;   // convbn inside Sequential: <name>.0.weight / <name>.1.*
+        const std::string wkey = d.tr ? fe + d.name + ".0.weight" : (d.bn ? fe + d.name + ".0.weight" : fe + d.name + ".weight");
+        (void)seq;
+        {   // Conv2D [cout][cin][3][3] / Conv2DTranspose [cin][cout][3][3]  ->  [tap][cin][cout]
+            const std::vector<float> &w = h->host.at(wkey);
+            std::vector<float> wt((size_t)9 * d.cin * d.cout);
+            for (int co = 0; co < d.cout; ++co)
+                for (int ci = 0; ci < d.cin; ++ci)
+                    for (int tap = 0; tap < 9; ++tap)
+                        wt[((size_t)tap * d.cin + ci) * d.cout + co] =
+                            d.tr ? w[((size_t)ci * d.cout + co) * 9 + tap] : w[((size_t)co * d.cin + ci) * 9 + tap];
+            o.fe[i].w = sb.put(wt);
+        }
+        o.fe[i].bn = d.bn;
+        if (d.bn) {
+            std::vector<float> s, t;
+            fold_bn(h, fe + d.name + ".1", s, t);
+            o.fe[i].s = sb.put(s);
+            o.fe[i].t = sb.put(t);
+        }
+    }
+    const char *r1n[2] = {"refinement1_left", "refinement1_disp"};
+    for (int k = 0; k < 2; ++k) {
+        const int cin = k == 0 ? 3 : 1;
+        const std::vector<float> &w = h->host.at(std::string(r1n[k]) + ".0.weight");   // [32][cin][3][3]
+        std::vector<float> wt(9 * cin * 32);
+        for (int co = 0; co < 32; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int tap = 0; tap < 9; ++tap) wt[(tap * cin + ci) * 32 + co] = w[(co * cin + ci) * 9 + tap];
+        o.r1_first[k] = sb.put(wt);
+        for (int b = 0; b < 4; ++b) pack_dws(h, sb, std::string(r1n[k]) + "." + std::to_string(b + 1), o.r1[k][b]);
+    }
+    {
+        std::vector<float> s, t;
+        fold_bn(h, "refinement2.0.0", s, t);
+        o.r2f_s = sb.put(s);
+        o.r2f_t = sb.put(t);
+        std::vector<float> wp(9 * 4 * 2 * 64 * 4);
+        pack_conv2d_mfma(h->host.at("refinement2.0.2.weight").data(), 64, 9, wp.data());   // [32][64][3][3]
+        o.r2f_w = sb.put(wp);
+    }
+    for (int b = 0; b < 4; ++b) pack_dws(h, sb, "refinement2." + std::to_string(b + 1), o.r2[b]);
+    {
+        const std::vector<float> &w = h->host.at("refinement2.5.weight");   // [1][32][3][3]
+        std::vector<float> wt(9 * 32);
+        for (int ci = 0; ci < 32; ++ci)
+            for (int tap = 0; tap < 9; ++tap) wt[tap * 32 + ci] = w[ci * 9 + tap];
+        o.r2_last = sb.put(wt);
+    }
+}
+
+static void bind_net2d(lws_ctx *h, const Net2dOffsets &o)
+{
+    Net2d &n = h->net2d;
+    for (int i = 0; i < 12; ++i) {
+        const auto &d = kFeLayers[i];
+        Conv2dLayer &l = n.fe[i];
+        l.cin = d.cin; l.cout = d.cout; l.stride = d.stride; l.pad = d.pad; l.dil = d.dil;
+        l.transposed = d.tr; l.relu = d.relu;
+        l.w = h->params + o.fe[i].w;
+        l.bn_s = d.bn ? h->params + o.fe[i].s : nullptr;
+        l.bn_t = d.bn ? h->params + o.fe[i].t : nullptr;
+    }
+    auto bind_dws = [&](RefDws &r, const Net2dOffsets::D &d, int dil) {
+        r.dil = dil;
+        r.bn_s = h->params + d.s; r.bn_t = h->params + d.t; r.dw = h->params + d.dw; r.pw = h->params + d.pw;
+    };
+    for (int k = 0; k < 2; ++k) {
+        n.r1_first[k] = h->params + o.r1_first[k];
+        for (int b = 0; b < 4; ++b) bind_dws(n.r1[k][b], o.r1[k][b], 2 << b);      // dilation 2,4,8,16 (submodules.py:298)
+    }
+    n.r2_first.bn_s = h->params + o.r2f_s;
+    n.r2_first.bn_t = h->params + o.r2f_t;
+    n.r2_first.w = h->params + o.r2f_w;
+    for (int b = 0; b < 4; ++b) bind_dws(n.r2[b], o.r2[b], 8 >> b);                 // dilation 8,4,2,1 (submodules.py:316)
+    n.r2_last = h->params + o.r2_last;
+}
+
+// feature_extraction.forward (submodules.py:176-188) on N images; first layer may read two separate inputs
+static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, int nA, int nB, int H, int W,
+                              const WsLayout &L, float *f8, float *f4, float *f2, hipStream_t st)
+{
+    const Net2d &n = h->net2d;
+    const int N = nA + nB, H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+    float *ws = h->ws;
+    float *a0 = ws + L.fe_a0, *o = ws + L.fe_o, *a2 = ws + L.fe_a2, *o2 = ws + L.fe_o2, *c1 = ws + L.fe_c1,
+          *pre = ws + L.fe_pre, *c3 = ws + L.fe_c3, *o3 = ws + L.fe_o3, *cls = ws + L.fe_cls;
+    int rc;
+#define LWS_FE(call)                                   \
+    {                                                  \
+        ProfScope p_(h, LWS_KC_FEATURE2D, st);         \
+        rc = (call);                                   \
+    }                                                  \
+    if (rc) return rc;
+    LWS_FE(launch_conv2d_nchw(n.fe[0], imgA, nullptr, a0, nA, H, W, st));                                   // dres0.0
+    if (nB > 0) LWS_FE(launch_conv2d_nchw(n.fe[0], imgB, nullptr, a0 + (size_t)nA * 4 * H2 * W2, nB, H, W, st));
+    LWS_FE(launch_conv2d_nchw(n.fe[1], a0, nullptr, o, N, H2, W2, st));                                     // dres0.2
+    LWS_FE(launch_conv2d_nchw(n.fe[2], o, nullptr, a2, N, H2, W2, st));                                     // dres1.0
+    LWS_FE(launch_conv2d_nchw(n.fe[3], a2, o, o2, N, H2, W2, st));                                          // dres1.2 + o   (:179)
+    LWS_FE(launch_conv2d_nchw(n.fe[4], o2, nullptr, c1, N, H2, W2, st));                                    // conv1 (1/4)
+    LWS_FE(launch_conv2d_nchw(n.fe[5], c1, nullptr, pre, N, H4, W4, st));                                   // conv2 -> pre
+    LWS_FE(launch_conv2d_nchw(n.fe[6], pre, nullptr, c3, N, H4, W4, st));                                   // conv3 (1/8)
+    LWS_FE(launch_conv2d_nchw(n.fe[7], c3, nullptr, f8, N, H8, W8, st));                                    // conv4 -> f8
+    LWS_FE(launch_conv2d_nchw(n.fe[8], f8, pre, f4, N, H8, W8, st));                                        // relu(conv5 + pre) (:103)
+    LWS_FE(launch_conv2d_nchw(n.fe[9], f4, o2, o3, N, H4, W4, st));                                         // conv6 + output (:106,:182)
+    LWS_FE(launch_conv2d_nchw(n.fe[10], o3, nullptr, cls, N, H2, W2, st));                                  // classif1.0
+    LWS_FE(launch_conv2d_nchw(n.fe[11], cls, nullptr, f2, N, H2, W2, st));                                  // classif1.2 -> f2
+#undef LWS_FE
+    return LWS_OK;
+}
+
+// models.py:158-162
+static int refine(lws_ctx *h, const float *left, const float *pred3, int B, int H, int W, const WsLayout &L,
+                  float *pred4, hipStream_t st)
+{
+    const Net2d &n = h->net2d;
+    float *ra = h->ws + L.r_a, *rb = h->ws + L.r_b, *rc_ = h->ws + L.r_c;
+    int rc;
+#define LWS_RF(kc, call)               \
+    {                                  \
+        ProfScope p_(h, kc, st);       \
+        rc = (call);                   \
+    }                                  \
+    if (rc) return rc;
+    // refinement1_left: left -> ra
+    LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(left, 3, n.r1_first[0], ra, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][0], ra, rc_, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][1], rc_, ra, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][2], ra, rc_, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][3], rc_, ra, B, H, W, st));
+    // refinement1_disp: pred3 -> rb
+    LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(pred3, 1, n.r1_first[1], rb, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][0], rb, rc_, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][1], rc_, rb, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][2], rb, rc_, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][3], rc_, rb, B, H, W, st));
+    // refinement2 on concat(ra, rb)
+    LWS_RF(LWS_KC_REF_CONV64, launch_ref_conv64(n.r2_first, ra, rb, rc_, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[0], rc_, ra, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[1], ra, rc_, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[2], rc_, ra, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[3], ra, rc_, B, H, W, st));
+    LWS_RF(LWS_KC_REF_LAST, launch_ref_last(rc_, n.r2_last, pred3, pred4, B, H, W, st));
+#undef LWS_RF
+    return LWS_OK;
+}
+
+static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *const featsR[3], int B, int H, int W,
+                       float *const pred_out[3], const WsLayout &L, hipStream_t st);
+
 }  // namespace lws
 
 using namespace lws;
+
+namespace lws {
+
+static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *const featsR[3], int B, int H, int W,
+                       float *const pred_out[3], const WsLayout &L, hipStream_t st)
+{
+    int rc;
+    float *act_a = h->ws + L.act_a, *act_b = h->ws + L.act_b, *raw = h->ws + L.cost_raw, *cost = h->ws + L.cost_out,
+          *low = h->ws + L.low;
+    static const int feat_c[3] = {16, 16, 8};   // feature_extraction outputs, submodules.py:101,104,186
+    for (int s = 0; s < 3; ++s) {
+        int D, hh, ww;
+        stage_dims(h, s, H, W, D, hh, ww);
+        if (s == 0) {
+            ProfScope p(h, LWS_KC_VOLUME_SHIFT, st);
+            rc = launch_volume_l1_shift(featsL[0], featsR[0], raw, B, feat_c[0], hh, ww, D, st);            // :131
+        } else {
+            ProfScope p(h, LWS_KC_VOLUME_WARP, st);
+            rc = launch_volume_l1_warp(featsL[s], featsR[s], pred_out[s - 1], raw, nullptr, B, feat_c[s], hh, ww, H, W,
+                                       h->cfg.maxdisplist[s], st);                                           // :119-127
+        }
+        if (rc) return rc;
+        rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st);                                  // :136-138
+        if (rc) return rc;
+        const float start = s == 0 ? 0.0f : (float)(-h->cfg.maxdisplist[s] + 1);
+        {
+            ProfScope p(h, LWS_KC_SOFTARGMIN, st);
+            rc = launch_softargmin(cost, low, B, D, hh, ww, start, st);                                      // :142,151
+        }
+        if (rc) return rc;
+        {
+            ProfScope p(h, LWS_KC_UPSAMPLE, st);
+            rc = launch_upsample_add(low, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], B, hh, ww, H, W, st);   // :145-156
+        }
+        if (rc) return rc;
+    }
+    return LWS_OK;
+}
+
+}  // namespace lws
 
 extern "C" {
 
@@ -288,7 +562,9 @@ int lws_profile_read(lws_handle h, double *total_ms, int64_t *launches)
 const char *lws_kernel_class_name(int kc)
 {
     static const char *names[LWS_KC_COUNT] = {"volume_l1_shift", "volume_l1_warp", "conv3d_first", "conv3d_mid16",
-                                              "conv3d_mid8",     "conv3d_last",    "softargmin",   "upsample_add"};
+                                              "conv3d_mid8",     "conv3d_last",    "softargmin",   "upsample_add",
+                                              "feature_conv2d",  "ref_first",      "ref_dws",      "ref_conv64",
+                                              "ref_last"};
     return kc >= 0 && kc < LWS_KC_COUNT ? names[kc] : "?";
 }
 
@@ -373,6 +649,10 @@ int lws_finalize(lws_handle h)
         }
     }
     al();
+    Net2dOffsets o2d;
+    h->have_2d = have_all_2d(h);
+    if (h->have_2d) build_net2d(h, slab, o2d);
+    al();
     if (h->params) LWS_HIP(hipFree(h->params));
     h->params = nullptr;
     LWS_HIP(hipMalloc(&h->params, slab.size() * sizeof(float)));
@@ -390,6 +670,7 @@ int lws_finalize(lws_handle h)
             l.bn_t = h->params + offs[i][j].t;
         }
     }
+    if (h->have_2d) bind_net2d(h, o2d);
     h->finalized = true;
     return LWS_OK;
 }
@@ -399,7 +680,7 @@ int lws_reserve(lws_handle h, int B, int H, int W)
     LWS_CHECK_ARG(h, "lws_reserve: null handle");
     int rc = check_size(h, B, H, W);
     if (rc) return rc;
-    return ensure_ws(h, ws_layout(h, B, H, W).total);
+    return ensure_ws(h, ws_layout(h, B, H, W).total_all);
 }
 
 int lws_volume_l1_shift(const float *L, const float *R, float *cost, int B, int C, int h, int w, int D, void *stream)
@@ -466,37 +747,65 @@ int lws_disparity_stages(lws_handle h, const float *const featsL[3], const float
     const WsLayout L = ws_layout(h, B, H, W);
     rc = ensure_ws(h, L.total);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    float *act_a = h->ws + L.act_a, *act_b = h->ws + L.act_b, *raw = h->ws + L.cost_raw, *cost = h->ws + L.cost_out,
-          *low = h->ws + L.low;
-    static const int feat_c[3] = {16, 16, 8};   // feature_extraction outputs, submodules.py:101,104,186
-    for (int s = 0; s < 3; ++s) {
-        int D, hh, ww;
-        stage_dims(h, s, H, W, D, hh, ww);
-        if (s == 0) {
-            ProfScope p(h, LWS_KC_VOLUME_SHIFT, st);
-            rc = launch_volume_l1_shift(featsL[0], featsR[0], raw, B, feat_c[0], hh, ww, D, st);            // :131
-        } else {
-            ProfScope p(h, LWS_KC_VOLUME_WARP, st);
-            rc = launch_volume_l1_warp(featsL[s], featsR[s], pred_out[s - 1], raw, nullptr, B, feat_c[s], hh, ww, H, W,
-                                       h->cfg.maxdisplist[s], st);                                           // :119-127
-        }
-        if (rc) return rc;
-        rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st);                                  // :136-138
-        if (rc) return rc;
-        const float start = s == 0 ? 0.0f : (float)(-h->cfg.maxdisplist[s] + 1);
-        {
-            ProfScope p(h, LWS_KC_SOFTARGMIN, st);
-            rc = launch_softargmin(cost, low, B, D, hh, ww, start, st);                                      // :142,151
-        }
-        if (rc) return rc;
-        {
-            ProfScope p(h, LWS_KC_UPSAMPLE, st);
-            rc = launch_upsample_add(low, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], B, hh, ww, H, W, st);   // :145-156
-        }
-        if (rc) return rc;
+    return stages_impl(h, featsL, featsR, B, H, W, pred_out, L, (hipStream_t)stream);
+}
+
+int lws_feature_extraction(lws_handle h, const float *img, int N, int H, int W, float *f8, float *f4, float *f2,
+                           void *stream)
+{
+    LWS_CHECK_ARG(h && img && f8 && f4 && f2, "feature_extraction: null pointer");
+    LWS_CHECK_ARG(N >= 1 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0,
+                  "feature_extraction: unsupported size N=%d %dx%d (H, W multiples of 8)", N, H, W);
+    if (!h->finalized || !h->have_2d) {
+        set_error("feature_extraction: the 2D network tensors were not all set before lws_finalize");
+        return LWS_ERR_STATE;
     }
-    return LWS_OK;
+    // workspace is planned per pair: N images = ceil(N/2) pairs
+    const WsLayout L = ws_layout(h, (N + 1) / 2, H, W);
+    int rc = ensure_ws(h, L.total_all);
+    if (rc) return rc;
+    return feature_extraction(h, img, nullptr, N, 0, H, W, L, f8, f4, f2, (hipStream_t)stream);
+}
+
+int lws_refine(lws_handle h, const float *left, const float *pred3, int B, int H, int W, float *pred4, void *stream)
+{
+    LWS_CHECK_ARG(h && left && pred3 && pred4, "refine: null pointer");
+    LWS_CHECK_ARG(B >= 1 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "refine: unsupported size B=%d %dx%d", B, H, W);
+    if (!h->finalized || !h->have_2d) {
+        set_error("refine: the 2D network tensors were not all set before lws_finalize");
+        return LWS_ERR_STATE;
+    }
+    const WsLayout L = ws_layout(h, B, H, W);
+    int rc = ensure_ws(h, L.total_all);
+    if (rc) return rc;
+    return refine(h, left, pred3, B, H, W, L, pred4, (hipStream_t)stream);
+}
+
+int lws_forward(lws_handle h, const float *left, const float *right, int B, int H, int W, float *const pred_out[4],
+                void *stream)
+{
+    LWS_CHECK_ARG(h && left && right && pred_out, "forward: null pointer");
+    for (int s = 0; s < 4; ++s) LWS_CHECK_ARG(pred_out[s], "forward: null output for stage %d", s + 1);
+    int rc = check_size(h, B, H, W);
+    if (rc) return rc;
+    if (!h->finalized || !h->have_2d) {
+        set_error("forward: set_state_dict/lws_finalize must be called with the full state dict first");
+        return LWS_ERR_STATE;
+    }
+    const WsLayout L = ws_layout(h, B, H, W);
+    rc = ensure_ws(h, L.total_all);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float *f8 = h->ws + L.fe_f8, *f4 = h->ws + L.fe_f4, *f2 = h->ws + L.fe_f2;
+    rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st);            // models.py:110-111
+    if (rc) return rc;
+    const size_t n8 = (size_t)B * 16 * (H / 8) * (W / 8), n4 = (size_t)B * 16 * (H / 4) * (W / 4),
+                 n2 = (size_t)B * 8 * (H / 2) * (W / 2);
+    const float *fl[3] = {f8, f4, f2};
+    const float *fr[3] = {f8 + n8, f4 + n4, f2 + n2};
+    rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st);                              // :115-156
+    if (rc) return rc;
+    return refine(h, left, pred_out[2], B, H, W, L, pred_out[3], st);                   // :158-162
 }
 
 }  // extern "C"

@@ -48,6 +48,36 @@ struct Stage3d {
     std::vector<Conv3dLayer> layers;   // layers_3d + 2
 };
 
+// One 3x3 layer of the 2D feature extractor (NCHW planes): conv or stride-2 transposed conv,
+// then BatchNorm (bn_s != nullptr) -> + residual -> ReLU.
+struct Conv2dLayer {
+    int cin = 0, cout = 0, stride = 1, pad = 1, dil = 1;
+    bool transposed = false, relu = false;
+    float *w = nullptr, *bn_s = nullptr, *bn_t = nullptr;
+};
+
+// Refinement: BatchNorm(32) -> ReLU -> depthwise 3x3 (dil) -> pointwise 32->32
+struct RefDws {
+    int dil = 1;
+    float *bn_s = nullptr, *bn_t = nullptr;
+    float *dw = nullptr;   // [tap][32]
+    float *pw = nullptr;   // MFMA A fragments [q][mt][lane][4]
+};
+
+struct RefConv64 {
+    float *bn_s = nullptr, *bn_t = nullptr;   // [64]
+    float *w = nullptr;                       // MFMA A fragments [tap][qq][mt][lane][4]
+};
+
+struct Net2d {
+    Conv2dLayer fe[12];          // feature extractor, in execution order
+    float *r1_first[2] = {nullptr, nullptr};   // refinement1_left / _disp first conv, [tap][cin][32]
+    RefDws r1[2][4];             // refinement1_{left,disp} blocks 1..4
+    RefConv64 r2_first;
+    RefDws r2[4];
+    float *r2_last = nullptr;    // [tap][32]
+};
+
 }  // namespace lws
 
 struct lws_prof_rec {
@@ -68,6 +98,8 @@ struct lws_ctx {
     float *params = nullptr;                                // one device slab for all packed params
     size_t params_bytes = 0;
     lws::Stage3d stage[3];
+    lws::Net2d net2d;
+    bool have_2d = false;                                   // all 2D tensors were given
     // activation workspace (grown by lws_reserve / on demand)
     float *ws = nullptr;
     size_t ws_bytes = 0;
@@ -91,6 +123,16 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
                       int w, hipStream_t st);
 int launch_conv3d_last(const Stage3d &s, const float *act_in, const float *cost_skip, float *cost_out, int B,
                        int D, int h, int w, hipStream_t st);
+
+// 2D networks (lws_conv2d.hip)
+int launch_conv2d_nchw(const Conv2dLayer &l, const float *in, const float *res, float *out, int N, int H, int W,
+                       hipStream_t st);
+int launch_ref_first(const float *in, int cin, const float *w, float *out, int B, int H, int W, hipStream_t st);
+int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, int W, hipStream_t st);
+int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, float *out, int B, int H, int W,
+                      hipStream_t st);
+int launch_ref_last(const float *in, const float *w, const float *pred3, float *out, int B, int H, int W, hipStream_t st);
+void pack_conv2d_mfma(const float *w, int cin, int ktaps, float *out);
 
 // host-side weight packing used by lws_finalize
 size_t packed_mid_weight_floats(int c3);

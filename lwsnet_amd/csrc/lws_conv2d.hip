@@ -1,0 +1,540 @@
+// 2D networks of LWSNet, float32, -ffp-contract=off.
+//
+//   feature extractor  /root/reference/models/submodules.py:5-33 (convbn/deconvbn), :35-109 (hourglass),
+//                      :113-188 (feature_extraction)            -> k_conv2d_nchw, k_deconv2d_s2_nchw
+//   refinement         submodules.py:223-327, models/models.py:158-162
+//                                                               -> k_ref_first, k_ref_dws, k_ref_conv64, k_ref_last
+//
+// Arithmetic contract (oracle/lws_oracle.c lwso_conv2d / lwso_deconv2d_s2 / lwso_bn_add_relu): every convolution
+// output is ONE fmaf chain from 0, taps (kh,kw) outer ascending, input channel inner ascending; zero padding
+// (fmaf(0, w, acc) == acc, so padded taps may be fed as zeros); BatchNorm(eval) = fmaf(x, s, t); then the residual
+// add; then ReLU.
+//
+// Layouts: the feature extractor works on planar NCHW maps with 3..16 channels (the volume kernels read its
+// outputs plane by plane, coalesced along W).  The refinement works on channels-last [B,H,W,32] maps: one pixel
+// = one 128-byte line, so dilated taps (dilation 2..16) and the strided "phase grid" tiles below always move whole
+// cache lines.
+#include <stdlib.h>
+
+#include "lws_common.h"
+
+namespace lws {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bn_relu2(float x, float s, float t) { return fmaxf(fmaf(x, s, t), 0.0f); }
+__device__ __forceinline__ float f4c(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+// =============================================================================================
+// Feature extractor: direct 3x3 convolution on NCHW planes, one thread = one output pixel x CPT output
+// channels (blockIdx.z enumerates (image, output-channel group) so that the small 1/4 and 1/8 resolution
+// layers still fill the chip).  Weights are stored [tap][cin][cout] and indexed wave-uniformly (scalar loads).
+// Epilogue: BatchNorm (optional) -> + residual (optional) -> ReLU (optional).
+// =============================================================================================
+template <int CIN, int CPT, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ in, const float *__restrict__ wgt,   // [tap][cin][COUT]
+                                                     const float *__restrict__ bn_s, const float *__restrict__ bn_t,
+                                                     const float *__restrict__ res, float *__restrict__ out, int COUT,
+                                                     int H, int W, int Ho, int Wo, int stride, int pad, int dil,
+                                                     int relu)
+{
+    const int groups = COUT / CPT;
+    const int b = blockIdx.z / groups, co0 = (blockIdx.z % groups) * CPT;   // wave-uniform: weights go through the scalar cache
+    const int ox = blockIdx.x * 64 + threadIdx.x, oy = blockIdx.y * 4 + threadIdx.y;
+    if (ox >= Wo || oy >= Ho) return;
+    const int64_t plane = (int64_t)H * W, oplane = (int64_t)Ho * Wo;
+    const float *inb = in + (int64_t)b * CIN * plane;
+    float acc[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) acc[c] = 0.0f;
+    // runtime tap loop: one iteration keeps CIN loads in flight and CPT accumulators live (a fully unrolled
+    // 9*CIN*CPT body makes hipcc hoist every load and spill)
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        int iy, ix;
+        bool ok;
+        if (TRANSPOSED) {          // oy = 2*iy - 1 + kh  (k3, s2, p1, output_padding 1)
+            const int ty = oy + 1 - kh, tx = ox + 1 - kw;
+            iy = ty >> 1;
+            ix = tx >> 1;
+            ok = ty >= 0 && !(ty & 1) && iy < H && tx >= 0 && !(tx & 1) && ix < W;
+        } else {
+            iy = oy * stride - pad + kh * dil;
+            ix = ox * stride - pad + kw * dil;
+            ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        }
+        const float *p = inb + (int64_t)(ok ? iy : 0) * W + (ok ? ix : 0);
+        const float *w = wgt + (int64_t)tap * CIN * COUT + co0;
+        float v[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) v[ci] = ok ? p[(int64_t)ci * plane] : 0.0f;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) acc[c] = fmaf(v[ci], w[ci * COUT + c], acc[c]);
+    }
+    const int64_t o = ((int64_t)b * COUT + co0) * oplane + (int64_t)oy * Wo + ox;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        float v = acc[c];
+        if (bn_s != nullptr) v = fmaf(v, bn_s[co0 + c], bn_t[co0 + c]);
+        if (res != nullptr) v = v + res[o + (int64_t)c * oplane];
+        if (relu) v = fmaxf(v, 0.0f);
+        out[o + (int64_t)c * oplane] = v;
+    }
+}
+
+template <int CIN, int CPT, bool TR>
+static void conv2d_launch(const Conv2dLayer &l, const float *in, const float *res, float *out, int N, int H, int W,
+                          int Ho, int Wo, hipStream_t st)
+{
+    dim3 grid(cdiv(Wo, 64), cdiv(Ho, 4), N * (l.cout / CPT)), block(64, 4);
+    hipLaunchKernelGGL((k_conv2d_nchw<CIN, CPT, TR>), grid, block, 0, st, in, l.w, l.bn_s, l.bn_t, res, out, l.cout, H,
+                       W, Ho, Wo, l.stride, l.pad, l.dil, l.relu ? 1 : 0);
+}
+
+// N images [N,cin,H,W] -> [N,cout,Ho,Wo]
+int launch_conv2d_nchw(const Conv2dLayer &l, const float *in, const float *res, float *out, int N, int H, int W,
+                       hipStream_t st)
+{
+    int Ho, Wo;
+    if (l.transposed) {
+        Ho = 2 * H;
+        Wo = 2 * W;
+    } else {
+        Ho = (H + 2 * l.pad - 2 * l.dil - 1) / l.stride + 1;
+        Wo = (W + 2 * l.pad - 2 * l.dil - 1) / l.stride + 1;
+    }
+    // output channels per thread: fewer at low resolution so that the grid still covers the chip
+    const int64_t px = (int64_t)N * Ho * Wo;
+    const int cpt = l.cout <= 4 ? l.cout : (px >= 49152 ? (l.cout >= 8 ? 8 : 4) : 4);
+#define LWS_C2D(CI, CP)                                                                               \
+    if (l.cin == CI && cpt == CP) {                                                                   \
+        if (l.transposed) conv2d_launch<CI, CP, true>(l, in, res, out, N, H, W, Ho, Wo, st);          \
+        else conv2d_launch<CI, CP, false>(l, in, res, out, N, H, W, Ho, Wo, st);                      \
+        LWS_LAUNCH_CHECK();                                                                           \
+        return LWS_OK;                                                                                \
+    }
+    LWS_C2D(3, 4) LWS_C2D(4, 8) LWS_C2D(4, 4) LWS_C2D(8, 4) LWS_C2D(8, 8) LWS_C2D(16, 4) LWS_C2D(16, 8)
+#undef LWS_C2D
+    set_error("conv2d_nchw: unsupported layer cin=%d cout=%d", l.cin, l.cout);
+    return LWS_ERR_INVALID;
+}
+
+// =============================================================================================
+// Refinement, first convolution: NCHW image (3 ch) or disparity (1 ch) -> channels-last [B,H,W,32], 3x3 pad 1,
+// no BatchNorm (submodules.py:284-291).  4 threads per pixel, 8 output channels each: a wave stores 16 whole lines.
+// =============================================================================================
+template <int CIN>
+__global__ __launch_bounds__(256) void k_ref_first(const float *__restrict__ in, const float *__restrict__ wgt,   // [tap][ci][32]
+                                                   float *__restrict__ out, int H, int W)
+{
+    __shared__ __attribute__((aligned(16))) float sW[9 * CIN * 32];
+    for (int i = threadIdx.x; i < 9 * CIN * 32; i += 256) sW[i] = wgt[i];
+    __syncthreads();
+    const int64_t plane = (int64_t)H * W;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pix = idx >> 2;
+    const int grp = (int)(idx & 3), b = blockIdx.y;
+    if (pix >= plane) return;
+    const int y = (int)(pix / W), x = (int)(pix % W);
+    const float *inb = in + (int64_t)b * CIN * plane;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int iy = y + kh - 1, ix = x + kw - 1;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float v = ok ? inb[(int64_t)ci * plane + (int64_t)iy * W + ix] : 0.0f;
+            const float4 w0 = *reinterpret_cast<const float4 *>(&sW[(tap * CIN + ci) * 32 + grp * 8]);
+            const float4 w1 = *reinterpret_cast<const float4 *>(&sW[(tap * CIN + ci) * 32 + grp * 8 + 4]);
+            acc[0] = fmaf(v, w0.x, acc[0]);
+            acc[1] = fmaf(v, w0.y, acc[1]);
+            acc[2] = fmaf(v, w0.z, acc[2]);
+            acc[3] = fmaf(v, w0.w, acc[3]);
+            acc[4] = fmaf(v, w1.x, acc[4]);
+            acc[5] = fmaf(v, w1.y, acc[5]);
+            acc[6] = fmaf(v, w1.z, acc[6]);
+            acc[7] = fmaf(v, w1.w, acc[7]);
+        }
+    }
+    float4 *o = reinterpret_cast<float4 *>(out + ((int64_t)b * plane + pix) * 32 + grp * 8);
+    o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+// =============================================================================================
+// Phase-grid tiles for dilated 3x3 layers.  With dilation d the taps of pixel (y,x) are (y +- d, x +- d): pixels
+// of the same phase (y mod d, x mod d) form an ordinary dense 3x3 problem on a grid subsampled by d.  A
+// workgroup owns RT_Y x RT_X pixels of ONE phase inside an image block of (RT_Y*d) x (RT_X*d) pixels, so its halo
+// is (RT_Y+2) x (RT_X+2) pixels for every dilation (1.56x read amplification instead of 9 re-reads), and every
+// pixel it touches is a whole 128-byte line of the channels-last map.
+// =============================================================================================
+constexpr int RT_Y = 8, RT_X = 16;                // tile: 8 rows of 16 pixels (one MFMA N-tile per row)
+constexpr int RH_Y = RT_Y + 2, RH_X = RT_X + 2;   // halo tile
+constexpr int RVS = 36;                           // LDS pixel stride in dwords (32 channels + 4 pad)
+
+struct RefTile {
+    int b, Y0, X0;
+};
+
+__device__ __forceinline__ RefTile ref_tile(int dil, int nbx, int nby)
+{
+    int bid = blockIdx.x;
+    const int d2 = dil * dil;
+    const int phase = bid % d2;
+    bid /= d2;
+    const int bx = bid % nbx;
+    bid /= nbx;
+    const int by = bid % nby;
+    RefTile t;
+    t.b = bid / nby;
+    t.Y0 = by * RT_Y * dil + phase / dil;
+    t.X0 = bx * RT_X * dil + phase % dil;
+    return t;
+}
+
+// =============================================================================================
+// Depthwise-separable block (submodules.py:238-261): BatchNorm(32) -> ReLU -> depthwise 3x3 (dilated) ->
+// pointwise 1x1 (32 -> 32), all in one kernel:
+//   1. stage the halo tile with BN+ReLU applied (out-of-image pixels are literal zeros = the conv padding);
+//   2. depthwise on VALU: one thread = (pixel, 4 channels), 9 float4 taps from LDS, result written to a second
+//      LDS image in MFMA B-operand order (4x4-transposed inside each 16-channel group, see lws_conv3d.hip);
+//   3. pointwise on fp32 MFMA: Out^T[cout, pixel] = W[cout, cin] * X[cin, pixel], K = 32 = 8 MFMAs per tile;
+//   4. store the raw result (the next block applies its own BatchNorm while staging).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, const float *__restrict__ bn_s,
+                                                 const float *__restrict__ bn_t, const float *__restrict__ dw,   // [tap][32]
+                                                 const float4 *__restrict__ pwpk,                              // [q][mt][lane]
+                                                 float *__restrict__ out, int H, int W, int dil, int nbx, int nby)
+{
+    __shared__ __attribute__((aligned(16))) float sA[RH_Y * RH_X * RVS];
+    __shared__ __attribute__((aligned(16))) float sB[RT_Y * RT_X * RVS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const RefTile t = ref_tile(dil, nbx, nby);
+    const float *inb = in + (int64_t)t.b * H * W * 32;
+
+    // pointwise A fragments (4 float4) and this thread's depthwise weights (9 float4: c4 = tid % 8 is fixed)
+    float4 aw[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) aw[q][mt] = pwpk[(q * 2 + mt) * 64 + lane];
+    const int c4 = tid & 7;
+    float4 wd[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wd[tap] = *reinterpret_cast<const float4 *>(dw + tap * 32 + c4 * 4);
+    const float4 s4 = *reinterpret_cast<const float4 *>(bn_s + c4 * 4);
+    const float4 t4 = *reinterpret_cast<const float4 *>(bn_t + c4 * 4);
+
+    // 1. stage: item = (halo pixel, 4-channel group); 180 * 8 = 1440 items
+    constexpr int ITEMS = RH_Y * RH_X * 8, SITER = (ITEMS + 255) / 256;
+    float4 c[SITER];
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int it = tid + i * 256;
+        const int hp = it >> 3;
+        const int hy = hp / RH_X, hx = hp % RH_X;
+        const int gy = t.Y0 + (hy - 1) * dil, gx = t.X0 + (hx - 1) * dil;
+        c[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it < ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const float4 v = *reinterpret_cast<const float4 *>(inb + ((int64_t)gy * W + gx) * 32 + c4 * 4);
+            c[i] = make_float4(bn_relu2(v.x, s4.x, t4.x), bn_relu2(v.y, s4.y, t4.y), bn_relu2(v.z, s4.z, t4.z),
+                               bn_relu2(v.w, s4.w, t4.w));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int it = tid + i * 256;
+        if (it < ITEMS) *reinterpret_cast<float4 *>(&sA[(it >> 3) * RVS + c4 * 4]) = c[i];
+    }
+    __syncthreads();
+
+    // 2. depthwise: 128 pixels x 8 groups = 1024 items, 4 per thread
+    {
+        const int q = c4 >> 2, a_ = c4 & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = (tid >> 3) + i * 32;
+            const int pi = p / RT_X, pj = p % RT_X;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float4 a = *reinterpret_cast<const float4 *>(&sA[((pi + kh) * RH_X + pj + kw) * RVS + c4 * 4]);
+                    const float4 w = wd[kh * 3 + kw];
+                    acc.x = fmaf(a.x, w.x, acc.x);
+                    acc.y = fmaf(a.y, w.y, acc.y);
+                    acc.z = fmaf(a.z, w.z, acc.z);
+                    acc.w = fmaf(a.w, w.w, acc.w);
+                }
+            float *d = &sB[p * RVS + 16 * q + a_];      // channel 16q + 4a_ + e -> dword 16q + 4e + a_
+            d[0] = acc.x;
+            d[4] = acc.y;
+            d[8] = acc.z;
+            d[12] = acc.w;
+        }
+    }
+    __syncthreads();
+
+    // 3. pointwise MFMA: wave handles tile rows 2*wave, 2*wave+1 x both output-channel tiles
+    const int n = lane & 15, g = lane >> 4;
+    floatx4 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    float4 bv[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            bv[r][q] = *reinterpret_cast<const float4 *>(&sB[((2 * wave + r) * RT_X + n) * RVS + 16 * q + 4 * g]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(aw[q][mt], j), f4c(bv[r][q], j), acc[r][mt], 0, 0, 0);
+
+    // 4. store: lane (n, g) holds channels 16mt + 4g .. +3 of pixel (row, n)
+    float *outb = out + (int64_t)t.b * H * W * 32;
+    const int gx = t.X0 + n * dil;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int gy = t.Y0 + (2 * wave + r) * dil;
+        if (gy < H && gx < W) {
+            float *o = outb + ((int64_t)gy * W + gx) * 32;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                *reinterpret_cast<float4 *>(o + mt * 16 + 4 * g) =
+                    make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
+        }
+    }
+}
+
+// =============================================================================================
+// refinement2[0] (submodules.py:304-309): BatchNorm(64) -> ReLU -> Conv 3x3 dilation 8, 64 -> 32, on the
+// concatenation [refined_left, refined_disp] (models.py:160) -- the concat is never materialised: the two
+// channels-last maps are staged side by side.  fp32-MFMA implicit GEMM, K = 9 taps x 64 channels = 144 MFMAs per
+// accumulator; weights streamed from L2 in fragment order one step ahead (same scheme as k_conv3d_mid16).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ inL, const float *__restrict__ inD,
+                                                    const float *__restrict__ bn_s, const float *__restrict__ bn_t,   // [64]
+                                                    const float4 *__restrict__ wpk,   // [tap][qq][mt][lane]
+                                                    float *__restrict__ out, int H, int W, int dil, int nbx, int nby)
+{
+    __shared__ __attribute__((aligned(16))) float sA[2 * RH_Y * RH_X * RVS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const RefTile t = ref_tile(dil, nbx, nby);
+    const int n = lane & 15, g = lane >> 4;
+
+    // stage: item = (tensor, halo pixel, 16-channel group): 2 * 180 * 2 = 720 items of 64 bytes
+    constexpr int NPX = RH_Y * RH_X, ITEMS = 2 * NPX * 2, SITER = (ITEMS + 255) / 256;
+    {
+        float4 c[SITER][4];
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * 256;
+            const int q = it & 1, hp = (it >> 1) % NPX, ten = (it >> 1) / NPX;
+            const int hy = hp / RH_X, hx = hp % RH_X;
+            const int gy = t.Y0 + (hy - 1) * dil, gx = t.X0 + (hx - 1) * dil;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            c[i][0] = c[i][1] = c[i][2] = c[i][3] = z;
+            if (it < ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const float *base = (ten == 0 ? inL : inD) + (int64_t)t.b * H * W * 32;
+                const float4 *src = reinterpret_cast<const float4 *>(base + ((int64_t)gy * W + gx) * 32 + q * 16);
+                const float4 *sp = reinterpret_cast<const float4 *>(bn_s + ten * 32 + q * 16);
+                const float4 *tp = reinterpret_cast<const float4 *>(bn_t + ten * 32 + q * 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 v = src[k], s = sp[k], tt = tp[k];
+                    c[i][k] = make_float4(bn_relu2(v.x, s.x, tt.x), bn_relu2(v.y, s.y, tt.y), bn_relu2(v.z, s.z, tt.z),
+                                          bn_relu2(v.w, s.w, tt.w));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * 256;
+            if (it < ITEMS) {
+                const int q = it & 1, hp = (it >> 1) % NPX, ten = (it >> 1) / NPX;
+                float4 *dst = reinterpret_cast<float4 *>(&sA[(ten * NPX + hp) * RVS + q * 16]);
+                dst[0] = make_float4(c[i][0].x, c[i][1].x, c[i][2].x, c[i][3].x);
+                dst[1] = make_float4(c[i][0].y, c[i][1].y, c[i][2].y, c[i][3].y);
+                dst[2] = make_float4(c[i][0].z, c[i][1].z, c[i][2].z, c[i][3].z);
+                dst[3] = make_float4(c[i][0].w, c[i][1].w, c[i][2].w, c[i][3].w);
+            }
+        }
+    }
+    const float4 *wp = wpk + lane;
+    float4 w_cur[4][2], w_nxt[4][2];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) w_cur[qq][mt] = wp[(qq * 2 + mt) * 64];
+    __syncthreads();
+
+    floatx4 acc[2][2];
+    int rbase[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        rbase[r] = ((2 * wave + r) * RH_X + n) * RVS + 4 * g;
+    }
+    // step = (tap, qq): qq = 2*tensor + 16-channel group -> input channels 16*qq .. 16*qq+15 of the concat
+    auto step_off = [](int tap, int qq) { return ((qq >> 1) * NPX + (tap / 3) * RH_X + tap % 3) * RVS + (qq & 1) * 16; };
+    float4 b_cur[2], b_nxt[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) b_cur[r] = *reinterpret_cast<const float4 *>(&sA[rbase[r] + step_off(0, 0)]);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int tn = tap < 8 ? tap + 1 : 8;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) w_nxt[qq][mt] = wp[((tn * 4 + qq) * 2 + mt) * 64];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int off_n = qq < 3 ? step_off(tap, qq + 1) : step_off(tn, 0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) b_nxt[r] = *reinterpret_cast<const float4 *>(&sA[rbase[r] + off_n]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(w_cur[qq][mt], j), f4c(b_cur[r], j), acc[r][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) b_cur[r] = b_nxt[r];
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) w_cur[qq][mt] = w_nxt[qq][mt];
+    }
+    float *outb = out + (int64_t)t.b * H * W * 32;
+    const int gx = t.X0 + n * dil;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int gy = t.Y0 + (2 * wave + r) * dil;
+        if (gy < H && gx < W) {
+            float *o = outb + ((int64_t)gy * W + gx) * 32;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                *reinterpret_cast<float4 *>(o + mt * 16 + 4 * g) =
+                    make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
+        }
+    }
+}
+
+// =============================================================================================
+// refinement2[5] + skip (submodules.py:318-325, models.py:161-162): Conv 3x3 pad 1, 32 -> 1, plus pred3.
+// One thread = one pixel; 9 taps x 32 channels from the channels-last map (8 float4 per tap).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_ref_last(const float *__restrict__ in, const float *__restrict__ wgt,   // [tap][32]
+                                                  const float *__restrict__ pred3, float *__restrict__ out, int H, int W)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const float *inb = in + (int64_t)b * H * W * 32;
+    float acc = 0.0f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int iy = y + kh - 1;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ix = x + kw - 1;
+            if (ix < 0 || ix >= W) continue;
+            const float4 *p = reinterpret_cast<const float4 *>(inb + ((int64_t)iy * W + ix) * 32);
+            const float *w = wgt + (kh * 3 + kw) * 32;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 a = p[c];
+                acc = fmaf(a.x, w[c * 4 + 0], acc);
+                acc = fmaf(a.y, w[c * 4 + 1], acc);
+                acc = fmaf(a.z, w[c * 4 + 2], acc);
+                acc = fmaf(a.w, w[c * 4 + 3], acc);
+            }
+        }
+    }
+    const int64_t o = ((int64_t)b * H + y) * W + x;
+    out[o] = acc + pred3[o];
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+int launch_ref_first(const float *in, int cin, const float *w, float *out, int B, int H, int W, hipStream_t st)
+{
+    dim3 grid((unsigned)(((int64_t)H * W * 4 + 255) / 256), B), block(256);
+    if (cin == 3) hipLaunchKernelGGL(k_ref_first<3>, grid, block, 0, st, in, w, out, H, W);
+    else if (cin == 1) hipLaunchKernelGGL(k_ref_first<1>, grid, block, 0, st, in, w, out, H, W);
+    else {
+        set_error("ref_first: unsupported cin %d", cin);
+        return LWS_ERR_INVALID;
+    }
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, int W, hipStream_t st)
+{
+    const int nbx = cdiv(W, RT_X * l.dil), nby = cdiv(H, RT_Y * l.dil);
+    dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
+    hipLaunchKernelGGL(k_ref_dws, grid, block, 0, st, in, l.bn_s, l.bn_t, l.dw, reinterpret_cast<const float4 *>(l.pw),
+                       out, H, W, l.dil, nbx, nby);
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, float *out, int B, int H, int W,
+                      hipStream_t st)
+{
+    const int dil = 8;
+    const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, RT_Y * dil);
+    dim3 grid(nbx * nby * dil * dil * B), block(256);
+    hipLaunchKernelGGL(k_ref_conv64, grid, block, 0, st, inL, inD, l.bn_s, l.bn_t, reinterpret_cast<const float4 *>(l.w),
+                       out, H, W, dil, nbx, nby);
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+int launch_ref_last(const float *in, const float *w, const float *pred3, float *out, int B, int H, int W, hipStream_t st)
+{
+    dim3 grid(cdiv(W, 64), cdiv(H, 4), B), block(64, 4);
+    hipLaunchKernelGGL(k_ref_last, grid, block, 0, st, in, w, pred3, out, H, W);
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+// [cout=32][cin][kh][kw] with cin in 16-channel groups -> A fragments [tap][qq][mt][lane][j]
+void pack_conv2d_mfma(const float *w, int cin, int ktaps, float *out)
+{
+    const int Q = cin / 16;
+    for (int tap = 0; tap < ktaps; ++tap)
+        for (int q = 0; q < Q; ++q)
+            for (int mt = 0; mt < 2; ++mt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = lane & 15, g = lane >> 4;
+                        const int co = 16 * mt + m, ci = 16 * q + 4 * j + g;
+                        out[((((size_t)tap * Q + q) * 2 + mt) * 64 + lane) * 4 + j] = w[((size_t)co * cin + ci) * ktaps + tap];
+                    }
+}
+
+}  // namespace lws

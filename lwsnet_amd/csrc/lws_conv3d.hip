@@ -14,6 +14,8 @@
 //   k_conv3d_mid16  C3 % 16 == 0     fp32 MFMA implicit GEMM, M = cout tile, N = 16 voxels along x
 //   k_conv3d_mid8   C3 == 8          fp32 MFMA, M = (x parity, cout) so that all 16 MFMA rows work
 //   k_conv3d_last   C3 -> 1 + skip   VALU (K = 27*C3)
+#include <stdlib.h>
+
 #include "lws_common.h"
 
 namespace lws {
@@ -21,6 +23,9 @@ namespace lws {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bn_relu(float x, float s, float t) { return fmaxf(fmaf(x, s, t), 0.0f); }
+
+// compile-time component select (j is always a constant after unrolling)
+__device__ __forceinline__ float f4(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
 // =============================================================================================
 // First layer: cost [B,D,h,w] -> act [B,D,h,w,C3].  One thread = one voxel, all C3 outputs.
@@ -108,34 +113,52 @@ __global__ __launch_bounds__(256) void k_conv3d_first(const float *__restrict__ 
 // Each wave owns TD*TY/4 rows x all C3/16 output-channel tiles: (TD*TY/4)*(C3/16) independent
 // accumulator chains, which covers the 40-cycle dependent-issue latency of the 32-cycle MFMA.
 // =============================================================================================
-template <int C3, int TD, int TY>
+template <int C3, int TD, int TY, int WR, int WM>
 struct Mid16Cfg {
-    static constexpr int MT = C3 / 16;          // output-channel tiles
+    static constexpr int MT = C3 / 16;          // output-channel tiles of the layer
     static constexpr int Q = C3 / 16;           // input-channel groups per tap
+    static constexpr int NW = WR * WM;          // waves per workgroup
+    static constexpr int NT = 64 * NW;
     static constexpr int ROWS = TD * TY;
-    static constexpr int RW = ROWS / 4;         // rows per wave
+    static constexpr int RW = ROWS / WR;        // rows per wave
+    static constexpr int MTW = MT / WM;         // output-channel tiles per wave
     static constexpr int HD = TD + 2, HY = TY + 2, HX = 18;
     static constexpr int VS = C3 + 4;           // LDS voxel stride in dwords
     static constexpr int NVOX = HD * HY * HX;
+    static constexpr int ITEMS = NVOX * Q;      // staging items: (voxel, 16-channel group)
+    static constexpr int SITER = (ITEMS + NT - 1) / NT;
     static constexpr int LDS_BYTES = NVOX * VS * 4;
-    static_assert(ROWS % 4 == 0, "rows must split over 4 waves");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(ROWS % WR == 0 && MT % WM == 0, "tile must split evenly over the waves");
+    static_assert(RW * MTW >= 2 || NW == 8, "need >= 2 independent accumulator chains per SIMD");
 };
 
-template <int C3, int TD, int TY>
-__global__ __launch_bounds__(256) void k_conv3d_mid16(const float *__restrict__ in,     // [B,D,h,w,C3]
-                                                      const float4 *__restrict__ wpk,   // packed A fragments
-                                                      const float *__restrict__ bn_s,   // next layer BN [C3]
-                                                      const float *__restrict__ bn_t,
-                                                      float *__restrict__ out, int D, int h, int w,
-                                                      int tiles_x, int tiles_y)
+// XCD-aware block -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD a
+// contiguous run of tiles; neighbouring tiles then find each other's halo voxels in the same L2.
+// Speed only: any placement is correct.
+__device__ __forceinline__ int xcd_tile(int b, int nb)
 {
-    using Cfg = Mid16Cfg<C3, TD, TY>;
-    constexpr int MT = Cfg::MT, Q = Cfg::Q, RW = Cfg::RW, HY = Cfg::HY, HX = Cfg::HX, VS = Cfg::VS;
+    const int q = nb >> 3, r = nb & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+template <int C3, int TD, int TY, int WR, int WM>
+__global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__restrict__ in,     // [B,D,h,w,C3]
+                                                              const float4 *__restrict__ wpk,   // packed A fragments
+                                                              const float *__restrict__ bn_s,   // next layer BN [C3]
+                                                              const float *__restrict__ bn_t,
+                                                              float *__restrict__ out, int D, int h, int w,
+                                                              int tiles_x, int tiles_y)
+{
+    using Cfg = Mid16Cfg<C3, TD, TY, WR, WM>;
+    constexpr int MT = Cfg::MT, Q = Cfg::Q, RW = Cfg::RW, MTW = Cfg::MTW, HY = Cfg::HY, HX = Cfg::HX, VS = Cfg::VS;
+    constexpr int NT = Cfg::NT, SITER = Cfg::SITER;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WM, wm = wave % WM;     // this wave's row group / output-channel group
     const int n = lane & 15, g = lane >> 4;
-    int tile = blockIdx.x;
+    int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = tile % tiles_x;
     tile /= tiles_x;
     const int ty = tile % tiles_y;
@@ -144,79 +167,103 @@ __global__ __launch_bounds__(256) void k_conv3d_mid16(const float *__restrict__ 
     const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * C3;
 
-    // ---- stage the halo tile: one item = (voxel, 16-channel group) = 64 contiguous bytes ----
-    for (int it = tid; it < Cfg::NVOX * Q; it += 256) {
-        const int q = it % Q, v = it / Q;
-        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
-        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0, c3 = c0;
-        if (gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w) {
-            const float4 *src = reinterpret_cast<const float4 *>(inb + (((int64_t)gd * h + gy) * w + gx) * C3 + q * 16);
-            c0 = src[0];
-            c1 = src[1];
-            c2 = src[2];
-            c3 = src[3];
+    // ---- stage the halo tile: one item = (voxel, 16-channel group) = 64 contiguous bytes.  All global loads
+    //      of a thread are issued first (SITER x 4 float4 in flight), then transposed 4x4 and written to LDS.
+    {
+        float4 c[SITER][4];
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * NT;
+            const int q = it % Q, v = it / Q;
+            const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+            const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const bool ok = it < Cfg::ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            c[i][0] = c[i][1] = c[i][2] = c[i][3] = z;
+            if (ok) {
+                const float4 *src = reinterpret_cast<const float4 *>(inb + (((int64_t)gd * h + gy) * w + gx) * C3 + q * 16);
+                c[i][0] = src[0];
+                c[i][1] = src[1];
+                c[i][2] = src[2];
+                c[i][3] = src[3];
+            }
         }
-        float4 *dst = reinterpret_cast<float4 *>(lds + v * VS + q * 16);
-        dst[0] = make_float4(c0.x, c1.x, c2.x, c3.x);
-        dst[1] = make_float4(c0.y, c1.y, c2.y, c3.y);
-        dst[2] = make_float4(c0.z, c1.z, c2.z, c3.z);
-        dst[3] = make_float4(c0.w, c1.w, c2.w, c3.w);
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * NT;
+            if (it < Cfg::ITEMS) {
+                const int q = it % Q, v = it / Q;
+                float4 *dst = reinterpret_cast<float4 *>(lds + v * VS + q * 16);
+                dst[0] = make_float4(c[i][0].x, c[i][1].x, c[i][2].x, c[i][3].x);
+                dst[1] = make_float4(c[i][0].y, c[i][1].y, c[i][2].y, c[i][3].y);
+                dst[2] = make_float4(c[i][0].z, c[i][1].z, c[i][2].z, c[i][3].z);
+                dst[3] = make_float4(c[i][0].w, c[i][1].w, c[i][2].w, c[i][3].w);
+            }
+        }
     }
+
+    // weights of this wave: [tap][q][mt][lane] float4, mt in [wm*MTW, (wm+1)*MTW)
+    const float4 *wp = wpk + (wm * MTW) * 64 + lane;
+    float4 w_cur[Q][MTW], w_nxt[Q][MTW];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) w_cur[q][mt] = wp[(q * MT + mt) * 64];
     __syncthreads();
 
-    floatx4 acc[RW][MT];
+    floatx4 acc[RW][MTW];
 #pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MTW; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
     // per-row LDS base of this lane: voxel (rd, ry, n) of the halo tile, channel quad g
     int rbase[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-        const int row = wave * RW + r;
+        const int row = wr * RW + r;
         const int rd = row / TY, ry = row % TY;
         rbase[r] = ((rd * HY + ry) * HX + n) * VS + 4 * g;
     }
 
-    const float4 *wp = wpk + lane;
-    float4 a_nxt[MT];
+    // Software pipeline: the weights of tap t+1 and the activation fragments of step s+1 are requested
+    // BEFORE the MFMAs of step s; the sched_barriers keep hipcc from sinking the loads to their first use
+    // (which would expose the full L2 / LDS latency at one wave per SIMD).
+    float4 b_cur[RW], b_nxt[RW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = wp[mt * 64];
+    for (int r = 0; r < RW; ++r) b_cur[r] = *reinterpret_cast<const float4 *>(lds + rbase[r]);
 
 #pragma unroll 1
-    for (int kd = 0; kd < 3; ++kd) {
-#pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh) {
+    for (int tap = 0; tap < 27; ++tap) {
+        const int tn = tap < 26 ? tap + 1 : 26;                      // next tap (clamped: last prefetch is unused)
+        const int toff = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * VS;
+        const int toff_n = (((tn / 9) * HY + (tn / 3) % 3) * HX + tn % 3) * VS;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int tap = (kd * 3 + kh) * 3 + kw;
-                const int toff = ((kd * HY + kh) * HX + kw) * VS;
+        for (int q = 0; q < Q; ++q)
 #pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    float4 a[MT];
+            for (int mt = 0; mt < MTW; ++mt) w_nxt[q][mt] = wp[((tn * Q + q) * MT + mt) * 64];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a[mt] = a_nxt[mt];
-                    const int step = tap * Q + q;
-                    if (step + 1 < 27 * Q) {
+        for (int q = 0; q < Q; ++q) {
+            const int off_n = (q + 1 < Q) ? toff + (q + 1) * 16 : toff_n;
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = wp[((step + 1) * MT + mt) * 64];
-                    }
+            for (int r = 0; r < RW; ++r) b_nxt[r] = *reinterpret_cast<const float4 *>(lds + rbase[r] + off_n);
+            __builtin_amdgcn_sched_barrier(0);
+            // j outermost: consecutive MFMAs hit RW*MTW different accumulators (40-cycle dependent latency)
 #pragma unroll
-                    for (int r = 0; r < RW; ++r) {
-                        const float4 bv = *reinterpret_cast<const float4 *>(lds + rbase[r] + toff + q * 16);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
-                            acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, bv.x, acc[r][mt], 0, 0, 0);
-                            acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, bv.y, acc[r][mt], 0, 0, 0);
-                            acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, bv.z, acc[r][mt], 0, 0, 0);
-                            acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, bv.w, acc[r][mt], 0, 0, 0);
-                        }
-                    }
-                }
-            }
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+                        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4(w_cur[q][mt], j), f4(b_cur[r], j), acc[r][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) b_cur[r] = b_nxt[r];
         }
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) w_cur[q][mt] = w_nxt[q][mt];
     }
 
     // ---- epilogue: D[i][j]: row i = 4*(lane>>4) + reg = output channel in the tile, col j = lane&15 = voxel.
@@ -225,13 +272,13 @@ __global__ __launch_bounds__(256) void k_conv3d_mid16(const float *__restrict__ 
     const int gx = x0 + n;
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-        const int row = wave * RW + r;
+        const int row = wr * RW + r;
         const int gd = d0 + row / TY, gy = y0 + row % TY;
         if (gd < D && gy < h && gx < w) {
             float *o = outb + (((int64_t)gd * h + gy) * w + gx) * C3;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int cb = mt * 16 + 4 * g;
+            for (int mt = 0; mt < MTW; ++mt) {
+                const int cb = (wm * MTW + mt) * 16 + 4 * g;
                 const float4 s = *reinterpret_cast<const float4 *>(bn_s + cb);
                 const float4 t = *reinterpret_cast<const float4 *>(bn_t + cb);
                 float4 v;
@@ -475,20 +522,21 @@ int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int
     return LWS_OK;
 }
 
-template <int C3, int TD, int TY>
+template <int C3, int TD, int TY, int WR, int WM>
 static int mid16_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w,
                         hipStream_t st)
 {
-    using Cfg = Mid16Cfg<C3, TD, TY>;
+    using Cfg = Mid16Cfg<C3, TD, TY, WR, WM>;
     static bool attr_set = false;
     if (!attr_set) {
-        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3d_mid16<C3, TD, TY>),
+        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3d_mid16<C3, TD, TY, WR, WM>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         attr_set = true;
     }
     const int tiles_x = cdiv(w, 16), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
-    hipLaunchKernelGGL((k_conv3d_mid16<C3, TD, TY>), grid, block, Cfg::LDS_BYTES, st, in,
+    block = dim3(Cfg::NT);
+    hipLaunchKernelGGL((k_conv3d_mid16<C3, TD, TY, WR, WM>), grid, block, Cfg::LDS_BYTES, st, in,
                        reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
                        s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y);
     LWS_LAUNCH_CHECK();
@@ -514,8 +562,20 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
 {
     switch (s.c3) {
         case 8: return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
-        case 16: return mid16_launch<16, 3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
-        case 32: return mid16_launch<32, 3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+        case 16: return mid16_launch<16, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st);
+        case 32: {
+            // tile/wave-layout variants (LWS_MID16_VARIANT is a development knob; default chosen by measurement)
+            static const int variant = [] {
+                const char *e = getenv("LWS_MID16_VARIANT");
+                return e ? atoi(e) : 0;
+            }();
+            switch (variant) {
+                case 1: return mid16_launch<32, 3, 4, 4, 2>(s, layer, act_in, act_out, B, D, h, w, st);
+                case 2: return mid16_launch<32, 3, 2, 2, 2>(s, layer, act_in, act_out, B, D, h, w, st);
+                case 3: return mid16_launch<32, 3, 8, 4, 2>(s, layer, act_in, act_out, B, D, h, w, st);
+                default: return mid16_launch<32, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st);
+            }
+        }
         default: set_error("conv3d: unsupported channel count %d (8, 16, 32)", s.c3); return LWS_ERR_INVALID;
     }
 }

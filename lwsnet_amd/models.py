@@ -2,9 +2,10 @@
 
 ``LWSNet(args)`` reads the same four namespace fields, ``set_state_dict`` takes the
 same structured keys, and ``model(left, right)`` returns the same list of four
-``[B,1,H,W]`` float32 full-resolution disparity maps.  The three volume stages
-(models.py:115-156) run in the hand-written HIP library behind the C ABI; this class
-only owns device buffers and the call sequence.  There is no CPU path.
+``[B,1,H,W]`` float32 full-resolution disparity maps.  The whole forward -- feature
+extractor, the three volume stages (models.py:115-156) and the refinement -- runs in
+the hand-written HIP library behind the C ABI (``lws_forward``); this class only owns
+device buffers.  There is no CPU path.
 """
 from __future__ import annotations
 
@@ -13,7 +14,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib, ops, submodules
+from . import _lib, ops
 from .synth import check_size
 from .weights import state_dict_spec
 
@@ -86,7 +87,7 @@ class LWSNet:
                            "lws_set_tensor")
             if self.device is not None:
                 _lib.check(lib.lws_finalize(self._h), "lws_finalize")
-                self._params = submodules.Params(sd, self.device)
+                self._params = True
         self._sd = sd
         return self
 
@@ -119,12 +120,7 @@ class LWSNet:
             raise ValueError(f"left/right shapes differ: {tuple(left.shape)} vs {tuple(right.shape)}")
         B, _, H, W = left.shape
         check_size(H, W, self.maxdisplist[0])
-        with torch.no_grad(), torch.cuda.device(self.device):
-            both = submodules.feature_extraction(torch.cat([left, right], 0), self._params)   # models.py:110-111
-            feats_l = [f[:B].contiguous() for f in both]
-            feats_r = [f[B:].contiguous() for f in both]
-            pred = ops.disparity_stages(self._h, feats_l, feats_r, H, W)                     # :115-156
-            pred.append(submodules.refine(left, pred[2], self._params))                       # :158-162
-        return pred
+        with torch.cuda.device(self.device):
+            return ops.forward(self._h, left, right)                                          # models.py:106-164
 
     __call__ = forward

@@ -118,3 +118,45 @@ def disparity_stages(handle, feats_l, feats_r, H, W):
                                             B, int(H), int(W), arr(*[t.data_ptr() for t in preds]), _stream()),
                    "lws_disparity_stages")
     return preds
+
+
+def feature_extraction(handle, img):
+    """feature_extraction (models/submodules.py:113-188): [N,3,H,W] -> [1/8 (16 ch), 1/4 (16 ch), 1/2 (8 ch)]."""
+    x = _dev(img, "img")
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f"img must be [N,3,H,W]; got {tuple(x.shape)}")
+    N, _, H, W = x.shape
+    f8 = torch.empty((N, 16, H // 8, W // 8), device=x.device, dtype=torch.float32)
+    f4 = torch.empty((N, 16, H // 4, W // 4), device=x.device, dtype=torch.float32)
+    f2 = torch.empty((N, 8, H // 2, W // 2), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.lws_feature_extraction(handle, _ptr(x), N, H, W, _ptr(f8), _ptr(f4), _ptr(f2), _stream()),
+                   "lws_feature_extraction")
+    return [f8, f4, f2]
+
+
+def refine(handle, left, pred3):
+    """models/models.py:158-162: pred4 = pred3 + refinement2(cat(refinement1_left(left), refinement1_disp(pred3)))."""
+    l, p3 = _dev(left, "left"), _dev(pred3, "pred3")
+    B, _, H, W = l.shape
+    if tuple(p3.shape) != (B, 1, H, W):
+        raise ValueError(f"pred3 must be {(B, 1, H, W)}; got {tuple(p3.shape)}")
+    out = torch.empty_like(p3)
+    lib = _lib.load()
+    with torch.cuda.device(l.device):
+        _lib.check(lib.lws_refine(handle, _ptr(l), _ptr(p3), B, H, W, _ptr(out), _stream()), "lws_refine")
+    return out
+
+
+def forward(handle, left, right):
+    """LWSNet.forward (models/models.py:106-164): list of 4 x [B,1,H,W]."""
+    l, r = _dev(left, "left"), _dev(right, "right")
+    B, _, H, W = l.shape
+    preds = [torch.empty((B, 1, H, W), device=l.device, dtype=torch.float32) for _ in range(4)]
+    arr = ctypes.c_void_p * 4
+    lib = _lib.load()
+    with torch.cuda.device(l.device):
+        _lib.check(lib.lws_forward(handle, _ptr(l), _ptr(r), B, H, W, arr(*[t.data_ptr() for t in preds]), _stream()),
+                   "lws_forward")
+    return preds

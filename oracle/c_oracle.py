@@ -143,3 +143,103 @@ def disparity_stages(feats_l, feats_r, H, W, sd, maxdisplist=(24, 5, 5), return_
         low = softargmin(cost, start)
         pred.append(upsample_add(low, pred[s - 1] if s else None, H, W))
     return (pred, costs) if return_costs else pred
+
+
+# ---------------------------------------------------------------------------------------------
+# 2D networks (feature extractor, refinement) composed from the C functions
+# ---------------------------------------------------------------------------------------------
+def conv2d(x, w, stride=1, pad=1, dil=1, pre=None, depthwise=False):
+    x, w = _c(x), _c(w)
+    B, Cin, H, W = x.shape
+    Cout, k = w.shape[0], w.shape[2]
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    y = np.empty((B, Cout, Ho, Wo), np.float32)
+    ps, pt = (_c(pre[0]), _c(pre[1])) if pre is not None else (None, None)
+    lib().lwso_conv2d(_p(x), _p(w), _p(ps), _p(pt), _p(y), B, Cin, Cout, H, W, Ho, Wo, k, stride, pad, dil,
+                      1 if depthwise else 0)
+    return y
+
+
+def deconv2d_s2(x, w):
+    x, w = _c(x), _c(w)
+    B, Cin, H, W = x.shape
+    Cout = w.shape[1]
+    y = np.empty((B, Cout, 2 * H, 2 * W), np.float32)
+    lib().lwso_deconv2d_s2(_p(x), _p(w), _p(y), B, Cin, Cout, H, W)
+    return y
+
+
+def bn_add_relu(x, st=None, add=None, relu=False):
+    x = _c(x)
+    B, C = x.shape[:2]
+    plane = int(np.prod(x.shape[2:]))
+    y = np.empty_like(x)
+    s, t = (_c(st[0]), _c(st[1])) if st is not None else (None, None)
+    lib().lwso_bn_add_relu(_p(x), _p(s), _p(t), _p(_c(add)) if add is not None else None, _p(y), B, C,
+                           ctypes.c_int64(plane), 1 if relu else 0)
+    return y
+
+
+def feature_extraction(x, sd):
+    """submodules.py:176-188 with convbn's padding rule (:14): [1/8 (16 ch), 1/4 (16 ch), 1/2 (8 ch)]."""
+    from lwsnet_amd.weights import bn_scale_shift as bn
+    fe = "feature_extraction"
+
+    def convbn(v, name, stride, pad, dil, add=None, relu=True):
+        y = conv2d(v, sd[f"{fe}.{name}.0.weight"], stride, dil if dil > 1 else pad, dil)
+        return bn_add_relu(y, bn(sd, f"{fe}.{name}.1"), add, relu)
+
+    def deconvbn(v, name, add, relu):
+        y = deconv2d_s2(v, sd[f"{fe}.{name}.0.weight"])
+        return bn_add_relu(y, bn(sd, f"{fe}.{name}.1"), add, relu)
+
+    o = convbn(x, "dres0.0", 2, 1, 2)
+    o = convbn(o, "dres0.2", 1, 1, 4)
+    r = convbn(o, "dres1.0", 1, 1, 2)
+    o = convbn(r, "dres1.2", 1, 1, 2, add=o, relu=False)
+    c1 = convbn(o, "dres2.conv1.0", 2, 1, 1)
+    pre = convbn(c1, "dres2.conv2.0", 1, 1, 1)
+    c3 = convbn(pre, "dres2.conv3.0", 2, 1, 1)
+    f8 = convbn(c3, "dres2.conv4.0", 1, 1, 1)
+    f4 = deconvbn(f8, "dres2.conv5", pre, True)
+    o = deconvbn(f4, "dres2.conv6", o, False)
+    o = convbn(o, "classif1.0", 1, 1, 1)
+    f2 = conv2d(o, sd[f"{fe}.classif1.2.weight"], 1, 1, 1)
+    return [f8, f4, f2]
+
+
+def refine(left, pred3, sd):
+    """models.py:158-162 + submodules.py:223-327: returns pred4 [B,1,H,W]."""
+    from lwsnet_amd.weights import bn_scale_shift as bn
+
+    def dws(v, prefix, dil):
+        v = conv2d(v, sd[prefix + ".2.weight"], 1, dil, dil, pre=bn(sd, prefix + ".0"), depthwise=True)
+        return conv2d(v, sd[prefix + ".3.weight"], 1, 0, 1)
+
+    def r1(v, name):
+        v = conv2d(v, sd[name + ".0.weight"], 1, 1, 1)
+        for k in range(4):
+            v = dws(v, f"{name}.{k + 1}", 2 ** (k + 1))
+        return v
+
+    rl = r1(left, "refinement1_left")
+    rd = r1(pred3, "refinement1_disp")
+    v = np.concatenate([rl, rd], 1)
+    v = conv2d(v, sd["refinement2.0.2.weight"], 1, 8, 8, pre=bn(sd, "refinement2.0.0"))
+    for i, k in enumerate(reversed(range(4))):
+        v = dws(v, f"refinement2.{i + 1}", 2 ** k)
+    v = conv2d(v, sd["refinement2.5.weight"], 1, 1, 1)
+    return bn_add_relu(v, None, pred3, False)        # pred[2] + disp_up (same-size resize is the identity)
+
+
+def forward(left, right, sd, maxdisplist=(24, 5, 5)):
+    """LWSNet.forward (models.py:106-164) entirely through the C restatement."""
+    left, right = _c(left), _c(right)
+    B, _, H, W = left.shape
+    both = feature_extraction(np.concatenate([left, right]), sd)
+    fl = [f[:B] for f in both]
+    fr = [f[B:] for f in both]
+    pred = disparity_stages(fl, fr, H, W, sd, maxdisplist)
+    pred.append(refine(left, pred[2], sd))
+    return pred

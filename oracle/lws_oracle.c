@@ -270,3 +270,93 @@ LWSO_API void lwso_upsample_add(const float *low, const float *prev, float *out,
             }
         }
 }
+
+/* =====================================================================================
+ * 2D networks: feature extractor
+ * (submodules.py:5-33,35-109,113-188) and refinement (submodules.py:223-327).
+ * Arithmetic contract for every 2D convolution: ONE fmaf chain from 0 per output,
+ * taps (kh,kw) outer ascending, input channel inner ascending; zero padding (skipped taps).
+ * ===================================================================================== */
+
+/* Conv2D, NCHW, square kernel k (1 or 3), groups in {1, Cin (depthwise, Cout == Cin)}.
+ * If pre_s != NULL the input is first mapped through a = max(fmaf(x, pre_s[ci], pre_t[ci]), 0)
+ * (BatchNorm2D -> ReLU in front of the convolution, submodules.py:223-280); padding stays zero. */
+LWSO_API void lwso_conv2d(const float *x, const float *wgt, const float *pre_s, const float *pre_t, float *y,
+                          int B, int Cin, int Cout, int H, int W, int Ho, int Wo, int k, int stride, int pad,
+                          int dil, int depthwise)
+{
+    const int64_t plane = (int64_t)H * W, oplane = (int64_t)Ho * Wo;
+    const int cin_g = depthwise ? 1 : Cin;
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int co = 0; co < Cout; ++co)
+            for (int oy = 0; oy < Ho; ++oy)
+                for (int ox = 0; ox < Wo; ++ox) {
+                    float acc = 0.0f;
+                    for (int kh = 0; kh < k; ++kh) {
+                        int iy = oy * stride - pad + kh * dil;
+                        if (iy < 0 || iy >= H) continue;
+                        for (int kw = 0; kw < k; ++kw) {
+                            int ix = ox * stride - pad + kw * dil;
+                            if (ix < 0 || ix >= W) continue;
+                            for (int cg = 0; cg < cin_g; ++cg) {
+                                int ci = depthwise ? co : cg;
+                                float v = x[((int64_t)b * Cin + ci) * plane + (int64_t)iy * W + ix];
+                                if (pre_s) v = fmaxf(fmaf(v, pre_s[ci], pre_t[ci]), 0.0f);
+                                acc = fmaf(v, wgt[(((int64_t)co * cin_g + cg) * k + kh) * k + kw], acc);
+                            }
+                        }
+                    }
+                    y[((int64_t)b * Cout + co) * oplane + (int64_t)oy * Wo + ox] = acc;
+                }
+}
+
+/* Conv2DTranspose k=3, stride=2, padding=1, output_padding=1 (submodules.py:25-32): Ho = 2H, Wo = 2W.
+ * Weight layout [Cin][Cout][3][3].  out[oy][ox] gathers in[iy][ix] with oy = 2*iy - 1 + kh. */
+LWSO_API void lwso_deconv2d_s2(const float *x, const float *wgt, float *y, int B, int Cin, int Cout, int H, int W)
+{
+    const int Ho = 2 * H, Wo = 2 * W;
+    const int64_t plane = (int64_t)H * W, oplane = (int64_t)Ho * Wo;
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int co = 0; co < Cout; ++co)
+            for (int oy = 0; oy < Ho; ++oy)
+                for (int ox = 0; ox < Wo; ++ox) {
+                    float acc = 0.0f;
+                    for (int kh = 0; kh < 3; ++kh) {
+                        int ty = oy + 1 - kh;
+                        if (ty < 0 || (ty & 1)) continue;
+                        int iy = ty >> 1;
+                        if (iy >= H) continue;
+                        for (int kw = 0; kw < 3; ++kw) {
+                            int tx = ox + 1 - kw;
+                            if (tx < 0 || (tx & 1)) continue;
+                            int ix = tx >> 1;
+                            if (ix >= W) continue;
+                            for (int ci = 0; ci < Cin; ++ci) {
+                                float v = x[((int64_t)b * Cin + ci) * plane + (int64_t)iy * W + ix];
+                                acc = fmaf(v, wgt[(((int64_t)ci * Cout + co) * 3 + kh) * 3 + kw], acc);
+                            }
+                        }
+                    }
+                    y[((int64_t)b * Cout + co) * oplane + (int64_t)oy * Wo + ox] = acc;
+                }
+}
+
+/* y = fmaf(x, s[c], t[c]) (if s != NULL); y += add (if add != NULL); y = max(y, 0) (if relu).  NCHW, in place ok. */
+LWSO_API void lwso_bn_add_relu(const float *x, const float *s, const float *t, const float *add, float *y,
+                               int B, int C, int64_t plane, int relu)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const int64_t o = ((int64_t)b * C + c) * plane;
+            for (int64_t i = 0; i < plane; ++i) {
+                float v = x[o + i];
+                if (s) v = fmaf(v, s[c], t[c]);
+                if (add) v = v + add[o + i];
+                if (relu) v = fmaxf(v, 0.0f);
+                y[o + i] = v;
+            }
+        }
+}

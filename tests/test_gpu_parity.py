@@ -163,8 +163,49 @@ def test_disparity_stages_bitexact_vs_c_oracle(dev, model):
     assert err[0] < 1e-3 and err[1] < 5e-3 and err[2] < 1e-2, err
 
 
+# ------------------------------------------------------------------ 2D networks
+@pytest.mark.parametrize("N,H,W", [(1, 64, 256), (2, 72, 200), (3, 32, 48)])
+def test_feature_extraction_bitexact(dev, model, N, H, W):
+    from lwsnet_amd import ops
+    from oracle import c_oracle as C
+    x = np.random.default_rng(3).standard_normal((N, 3, H, W)).astype(np.float32)
+    got = ops.feature_extraction(model._h, cu(x, dev))
+    want = C.feature_extraction(x, model.state_dict())
+    for name, g, w in zip(("f8", "f4", "f2"), got, want):
+        assert_bits(g, w, f"feature_extraction {name}")
+
+
+def test_feature_extraction_golden(dev, model):
+    from lwsnet_amd import ops
+    g = golden("e2e_64x256.npz")
+    got = ops.feature_extraction(model._h, cu(g["left"], dev))
+    for i in range(3):
+        np.testing.assert_allclose(got[i].cpu().numpy(), g[f"featL{i}"], rtol=0, atol=3e-5)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 64, 256), (2, 40, 72), (1, 136, 152)])
+def test_refine_bitexact(dev, model, B, H, W):
+    from lwsnet_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.default_rng(9)
+    left = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    pred3 = (rng.random((B, 1, H, W)) * 150.0).astype(np.float32)
+    got = ops.refine(model._h, cu(left, dev), cu(pred3, dev))
+    assert_bits(got, C.refine(left, pred3, model.state_dict()), "refine")
+
+
+def test_forward_bitexact_vs_c_oracle(dev, model):
+    """The complete forward (features, 3 volume stages, refinement) equals the C oracle bit for bit."""
+    from oracle import c_oracle as C
+    g = golden("e2e_64x256.npz")
+    pred = model(g["left"], g["right"])
+    want = C.forward(g["left"], g["right"], model.state_dict())
+    for s in range(4):
+        assert_bits(pred[s], want[s], f"forward stage {s + 1}")
+
+
 def test_forward_matches_literal_oracle(dev, model):
-    """LWSNet.forward end to end (2D networks through PyTorch-ROCm plumbing) vs the golden stage maps."""
+    """LWSNet.forward end to end (all kernels native) vs the literal oracle's golden stage maps."""
     g = golden("e2e_64x256.npz")
     pred = model(g["left"], g["right"])
     assert len(pred) == 4 and all(tuple(p.shape) == (1, 1, 64, 256) and p.dtype == torch.float32 for p in pred)
@@ -178,10 +219,9 @@ def test_forward_matches_literal_oracle(dev, model):
 
 def test_hot_path_full_size_properties(dev, model):
     """BASELINE config 2/4 sizes: size-independent properties instead of a slow CPU oracle run."""
-    from lwsnet_amd import ops, submodules
+    from lwsnet_amd import ops
     left, right = make_batch(2, 256, 512, 0)
-    with torch.no_grad():
-        both = submodules.feature_extraction(cu(np.concatenate([left, right]), dev), model._params)
+    both = ops.feature_extraction(model._h, cu(np.concatenate([left, right]), dev))
     fl = [f[:2].contiguous() for f in both]
     fr = [f[2:].contiguous() for f in both]
     p2 = ops.disparity_stages(model._h, fl, fr, 256, 512)
@@ -197,6 +237,11 @@ def test_hot_path_full_size_properties(dev, model):
     assert all(torch.isfinite(p).all() for p in same)
     full = model(left, right)
     assert len(full) == 4 and all(tuple(p.shape) == (2, 1, 256, 512) and torch.isfinite(p).all() for p in full)
+    for s in range(3):                                # lws_forward == feature_extraction + stages, bitwise
+        assert torch.equal(full[s], p2[s]), s
+    for b in range(2):                                # whole forward is batch-invariant too
+        one = model(left[b:b + 1], right[b:b + 1])
+        assert all(torch.equal(one[s], full[s][b:b + 1]) for s in range(4)), b
 
 
 def test_forward_rejects_bad_sizes(dev, model):
