@@ -30,6 +30,28 @@ H, W = 256, 512
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
 
 
+def _with_traffic(roof, B):
+    """roofline.traffic: HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary
+    (profiles/r*/pmc_fetch_write_b1_256x512.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the B=1 workload it was collected on."""
+    if roof is None or B != 1:
+        return roof
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_fetch_write_b1_256x512.json")))
+    if not files:
+        return roof
+    try:
+        with open(files[-1]) as f:
+            ks = json.load(f)["kernels"]
+        for name, v in ks.items():
+            if "k_conv3d_mid16" in name and "FETCH_SIZE_KB_avg" in v and "WRITE_SIZE_KB_avg" in v:
+                roof["traffic"] = round((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024.0)
+                roof["traffic_source"] = os.path.relpath(files[-1], ROOT)
+    except Exception:
+        pass
+    return roof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +94,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    _lib.check(lib.lws_profile_enable(model._h, 1), "lws_profile_enable")
+    # inside the timed region only the dominant kernel class is bracketed by hipEvents (8 events per step);
+    # the per-class breakdown comes from a separate, untimed pass below
+    KC_MID16 = 3
+    _lib.check(lib.lws_profile_enable(model._h, 1 << KC_MID16), "lws_profile_enable")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -86,6 +111,14 @@ def main():
     tot = (ctypes.c_double * _lib.LWS_KC_COUNT)()
     cnt = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
     _lib.check(lib.lws_profile_read(model._h, tot, cnt), "lws_profile_read")
+    mid_avg_us = 1e3 * tot[KC_MID16] / max(cnt[KC_MID16], 1)
+    # untimed breakdown pass: every kernel class, 10 steps
+    nb = 10
+    _lib.check(lib.lws_profile_enable(model._h, -1), "lws_profile_enable")
+    for _ in range(nb):
+        step()
+    torch.cuda.synchronize()
+    _lib.check(lib.lws_profile_read(model._h, tot, cnt), "lws_profile_read")
     _lib.check(lib.lws_profile_enable(model._h, 0), "lws_profile_enable")
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -95,15 +128,16 @@ def main():
     kernels = {}
     for kc in range(_lib.LWS_KC_COUNT):
         if cnt[kc]:
-            kernels[lib.lws_kernel_class_name(kc).decode()] = {"launches_per_step": cnt[kc] / args.steps,
+            kernels[lib.lws_kernel_class_name(kc).decode()] = {"launches_per_step": cnt[kc] / nb,
                                                                "avg_us": 1e3 * tot[kc] / cnt[kc]}
-    hot_ms = sum(tot) / args.steps
+    hot_ms = sum(tot[kc] for kc in range(8)) / nb
+    all_ms = sum(tot) / nb
 
     # dominant kernel: stage-1 Conv3D c3 -> c3 (k_conv3d_mid16): 2*27*c3*c3 FLOP per voxel, voxels = B*D1*(H/8)*(W/8)
     c3 = margs.channels_3d * margs.growth_rate[0]
     vox = B * margs.maxdisplist[0] * (H // 8) * (W // 8)
     flop_per_launch = 2.0 * 27 * c3 * c3 * vox
-    mid = kernels.get("conv3d_mid16")
+    mid = {"avg_us": mid_avg_us} if mid_avg_us > 0 else None
     roof = None
     if mid:
         achieved = flop_per_launch / (mid["avg_us"] * 1e-6) / 1e12
@@ -119,9 +153,22 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         from oracle import lws_oracle                      # checker only: the CPU leg of the report
-        torch.set_num_threads(os.cpu_count() or 1)
         l1, r1 = left_np[:1], right_np[:1]
-        lws_oracle.forward(l1, r1, sd)                     # warm-up
+        # torch-CPU oversubscribes badly on many-core hosts (256 threads: 47 s per pair): probe a few thread
+        # counts with one forward each and keep the fastest, then time 3 forwards with it
+        ncpu = os.cpu_count() or 1
+        best_t, best_n = None, 1
+        for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+            torch.set_num_threads(n)
+            lws_oracle.forward(l1, r1, sd)                 # warm-up for this thread count
+            t1 = time.perf_counter()
+            lws_oracle.forward(l1, r1, sd)
+            dt = time.perf_counter() - t1
+            if best_t is None or dt < best_t:
+                best_t, best_n = dt, n
+            if dt > 8.0:
+                break
+        torch.set_num_threads(best_n)
         ts = []
         for _ in range(3):
             t1 = time.perf_counter()
@@ -130,8 +177,8 @@ def main():
         med = sorted(ts)[1]
         err = [float((pred[s][:1].cpu() - ref[s]).abs().max()) for s in range(4)]
         cpu = {"value": round(1.0 / med, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"3 forwards of 1 pair {H}x{W} after 1 warm-up, median; literal oracle on torch-CPU "
-                         f"{torch.__version__} (Paddle-CPU stand-in)",
+               "sample": f"3 forwards of 1 pair {H}x{W}, median, after probing 8/16/32/64 threads (host has {ncpu} logical "
+                         f"CPUs); literal oracle on torch-CPU {torch.__version__} (Paddle-CPU stand-in)",
                "max_abs_vs_gpu_per_stage": [round(e, 6) for e in err]}
 
     pairs = world * B * args.steps
@@ -143,8 +190,8 @@ def main():
         "config": {"workload": f"BASELINE config 2: batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[24,5,5], all 4 stages",
                    "pairs_per_gpu": B, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4" if world > 1 else "single GPU",
                    "weights": "seeded synthetic (seed 7, calibrated BN)"},
-        "roofline": roof, "cpu_baseline": cpu,
-        "hot_path_ms_per_step": round(hot_ms, 4), "kernels": {k: {a: round(b, 2) for a, b in v.items()} for k, v in kernels.items()},
+        "roofline": _with_traffic(roof, B), "cpu_baseline": cpu,
+        "hot_path_kernel_ms_per_step": round(hot_ms, 4), "all_kernel_ms_per_step": round(all_ms, 4), "kernels": {k: {a: round(b, 2) for a, b in v.items()} for k, v in kernels.items()},
     }
     print(json.dumps(out), flush=True)
     if world > 1:

@@ -137,10 +137,10 @@ typedef enum {
     LWS_KC_COUNT = 13
 } lws_kernel_class;
 
-/* on != 0: every kernel the handle launches from now on is bracketed by a hipEvent pair recorded on
- * the launch stream (records are dropped, never blocking, beyond 65536 launches).  on == 0: stop.
- * Either way the accumulated records are cleared. */
-int lws_profile_enable(lws_handle h, int on);
+/* class_mask != 0: every launch whose kernel class bit (1 << lws_kernel_class) is set is bracketed from now
+ * on by a hipEvent pair recorded on the launch stream (records are dropped, never blocking, beyond 65536
+ * launches); -1 selects all classes.  class_mask == 0: stop.  Either way the accumulated records are cleared. */
+int lws_profile_enable(lws_handle h, int class_mask);
 /* Synchronises the recorded events and returns, per kernel class, the summed device time in
  * milliseconds and the number of launches.  Both arrays have LWS_KC_COUNT entries. */
 int lws_profile_read(lws_handle h, double *total_ms, int64_t *launches);

@@ -193,7 +193,7 @@ struct ProfScope {
     bool live;
     ProfScope(lws_ctx *h_, int kc, hipStream_t st_) : h(h_), st(st_), live(false)
     {
-        if (!h->prof_on || h->prof.size() >= kMaxProfRecords) return;
+        if (!((h->prof_mask >> kc) & 1u) || h->prof.size() >= kMaxProfRecords) return;
         rec.kc = kc;
         rec.t0 = prof_event(h);
         rec.t1 = prof_event(h);
@@ -216,8 +216,10 @@ static void prof_clear(lws_ctx *h)
     h->prof.clear();
 }
 
+// low != nullptr: the soft-argmin is wanted too; *fused tells the caller whether it was done here
 static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost_out, float *act_a, float *act_b,
-                        int B, int D, int hh, int ww, hipStream_t st)
+                        int B, int D, int hh, int ww, hipStream_t st, float *low = nullptr, float start = 0.f,
+                        bool *fused = nullptr)
 {
     const Stage3d &s = h->stage[stage];
     int rc;
@@ -236,6 +238,11 @@ static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost
         std::swap(src, dst);
     }
     ProfScope p(h, LWS_KC_CONV3D_LAST, st);
+    if (low != nullptr && conv3d_last_can_fuse(s, D)) {
+        *fused = true;
+        return launch_conv3d_last_softargmin(s, src, cost_in, nullptr, low, start, B, D, hh, ww, st);
+    }
+    if (fused) *fused = false;
     return launch_conv3d_last(s, src, cost_in, cost_out, B, D, hh, ww, st);
 }
 
@@ -410,41 +417,48 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
     return LWS_OK;
 }
 
-// models.py:158-162
-static int refine(lws_ctx *h, const float *left, const float *pred3, int B, int H, int W, const WsLayout &L,
-                  float *pred4, hipStream_t st)
-{
-    const Net2d &n = h->net2d;
-    float *ra = h->ws + L.r_a, *rb = h->ws + L.r_b, *rc_ = h->ws + L.r_c;
-    int rc;
 #define LWS_RF(kc, call)               \
     {                                  \
         ProfScope p_(h, kc, st);       \
         rc = (call);                   \
     }                                  \
     if (rc) return rc;
-    // refinement1_left: left -> ra
+
+// refinement1_left(left) (models.py:158): depends on the left image only -> result in r_a (r_c is its scratch)
+static int refine_left(lws_ctx *h, const float *left, int B, int H, int W, const WsLayout &L, hipStream_t st)
+{
+    const Net2d &n = h->net2d;
+    float *ra = h->ws + L.r_a, *rc_ = h->ws + L.r_c;
+    int rc;
     LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(left, 3, n.r1_first[0], ra, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][0], ra, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][1], rc_, ra, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][2], ra, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][3], rc_, ra, B, H, W, st));
-    // refinement1_disp: pred3 -> rb
+    return LWS_OK;
+}
+
+// models.py:159-162: refinement1_disp(pred3), refinement2(concat), + pred3.  Needs refine_left's result in r_a.
+static int refine_rest(lws_ctx *h, const float *pred3, int B, int H, int W, const WsLayout &L, float *pred4,
+                       hipStream_t st)
+{
+    const Net2d &n = h->net2d;
+    float *ra = h->ws + L.r_a, *rb = h->ws + L.r_b, *rc_ = h->ws + L.r_c;
+    int rc;
     LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(pred3, 1, n.r1_first[1], rb, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][0], rb, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][1], rc_, rb, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][2], rb, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][3], rc_, rb, B, H, W, st));
-    // refinement2 on concat(ra, rb)
     LWS_RF(LWS_KC_REF_CONV64, launch_ref_conv64(n.r2_first, ra, rb, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[0], rc_, ra, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[1], ra, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[2], rc_, ra, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[3], ra, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_LAST, launch_ref_last(rc_, n.r2_last, pred3, pred4, B, H, W, st));
-#undef LWS_RF
     return LWS_OK;
 }
+#undef LWS_RF
 
 static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *const featsR[3], int B, int H, int W,
                        float *const pred_out[3], const WsLayout &L, hipStream_t st);
@@ -474,10 +488,11 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
                                        h->cfg.maxdisplist[s], st);                                           // :119-127
         }
         if (rc) return rc;
-        rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st);                                  // :136-138
-        if (rc) return rc;
         const float start = s == 0 ? 0.0f : (float)(-h->cfg.maxdisplist[s] + 1);
-        {
+        bool fused = false;
+        rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st, low, start, &fused);              // :136-138
+        if (rc) return rc;
+        if (!fused) {
             ProfScope p(h, LWS_KC_SOFTARGMIN, st);
             rc = launch_softargmin(cost, low, B, D, hh, ww, start, st);                                      // :142,151
         }
@@ -534,11 +549,11 @@ int lws_create(const lws_config *cfg, lws_handle *out)
     return LWS_OK;
 }
 
-int lws_profile_enable(lws_handle h, int on)
+int lws_profile_enable(lws_handle h, int class_mask)
 {
     LWS_CHECK_ARG(h, "lws_profile_enable: null handle");
     prof_clear(h);
-    h->prof_on = on != 0;
+    h->prof_mask = (unsigned)class_mask;
     return LWS_OK;
 }
 
@@ -573,6 +588,12 @@ int lws_destroy(lws_handle h)
     if (!h) return LWS_OK;
     prof_clear(h);
     for (hipEvent_t e : h->evt_pool) (void)hipEventDestroy(e);
+    if (h->side) {
+        (void)hipStreamSynchronize(h->side);
+        (void)hipStreamDestroy(h->side);
+        (void)hipEventDestroy(h->ev_fork);
+        (void)hipEventDestroy(h->ev_join);
+    }
     if (h->params) (void)hipFree(h->params);
     if (h->ws) (void)hipFree(h->ws);
     delete h;
@@ -778,7 +799,9 @@ int lws_refine(lws_handle h, const float *left, const float *pred3, int B, int H
     const WsLayout L = ws_layout(h, B, H, W);
     int rc = ensure_ws(h, L.total_all);
     if (rc) return rc;
-    return refine(h, left, pred3, B, H, W, L, pred4, (hipStream_t)stream);
+    rc = refine_left(h, left, B, H, W, L, (hipStream_t)stream);
+    if (rc) return rc;
+    return refine_rest(h, pred3, B, H, W, L, pred4, (hipStream_t)stream);
 }
 
 int lws_forward(lws_handle h, const float *left, const float *right, int B, int H, int W, float *const pred_out[4],
@@ -796,6 +819,18 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     rc = ensure_ws(h, L.total_all);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    // refinement1_left depends on the left image only: it runs on a side stream, concurrently with the feature
+    // extractor and the three volume stages, and joins before the rest of the refinement (speed only).
+    if (!h->side) {
+        LWS_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        LWS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        LWS_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    LWS_HIP(hipEventRecord(h->ev_fork, st));
+    LWS_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    rc = refine_left(h, left, B, H, W, L, h->side);                                     // models.py:158
+    if (rc) return rc;
+    LWS_HIP(hipEventRecord(h->ev_join, h->side));
     float *f8 = h->ws + L.fe_f8, *f4 = h->ws + L.fe_f4, *f2 = h->ws + L.fe_f2;
     rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st);            // models.py:110-111
     if (rc) return rc;
@@ -805,7 +840,8 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     const float *fr[3] = {f8 + n8, f4 + n4, f2 + n2};
     rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st);                              // :115-156
     if (rc) return rc;
-    return refine(h, left, pred_out[2], B, H, W, L, pred_out[3], st);                   // :158-162
+    LWS_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    return refine_rest(h, pred_out[2], B, H, W, L, pred_out[3], st);                    // :159-162
 }
 
 }  // extern "C"

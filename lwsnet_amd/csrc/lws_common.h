@@ -87,7 +87,7 @@ struct lws_prof_rec {
 
 struct lws_ctx {
     lws_config cfg;
-    bool prof_on = false;
+    unsigned prof_mask = 0;                  // kernel classes being timed
     std::vector<lws_prof_rec> prof;          // records of the current session
     std::vector<hipEvent_t> evt_pool;        // events available for reuse
     int device = 0;
@@ -103,6 +103,9 @@ struct lws_ctx {
     // activation workspace (grown by lws_reserve / on demand)
     float *ws = nullptr;
     size_t ws_bytes = 0;
+    // side stream for the branch of the forward that depends on the left image only
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace lws {
@@ -133,6 +136,10 @@ int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, fl
                       hipStream_t st);
 int launch_ref_last(const float *in, const float *w, const float *pred3, float *out, int B, int H, int W, hipStream_t st);
 void pack_conv2d_mfma(const float *w, int cin, int ktaps, float *out);
+
+bool conv3d_last_can_fuse(const Stage3d &s, int D);
+int launch_conv3d_last_softargmin(const Stage3d &s, const float *act_in, const float *cost_skip, float *cost_out,
+                                  float *low, float start, int B, int D, int h, int w, hipStream_t st);
 
 // host-side weight packing used by lws_finalize
 size_t packed_mid_weight_floats(int c3);

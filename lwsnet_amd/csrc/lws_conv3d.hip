@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "lws_common.h"
+#include "lws_device_math.h"
 
 namespace lws {
 
@@ -28,7 +29,7 @@ __device__ __forceinline__ float bn_relu(float x, float s, float t) { return fma
 __device__ __forceinline__ float f4(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
 // =============================================================================================
-// First layer: cost [B,D,h,w] -> act [B,D,h,w,C3].  One thread = one voxel, all C3 outputs.
+// First layer: cost [B,D,h,w] -> act [B,D,h,w,C3].  One thread = one voxel x 8 output channels.
 // The 27 input taps come straight from L2 (the volume is at most a few MB); weights are broadcast
 // from LDS as [tap][cout].
 // =============================================================================================
@@ -41,6 +42,8 @@ __global__ __launch_bounds__(256) void k_conv3d_first(const float *__restrict__ 
                                                       const float *__restrict__ bn_t,
                                                       float *__restrict__ act, int D, int h, int w)
 {
+    // C3/8 threads per voxel, 8 output channels each: a wave stores whole 32 B / 128 B voxel lines.
+    constexpr int G = C3 / 8;
     __shared__ __attribute__((aligned(16))) float sW[27 * C3];
     for (int i = threadIdx.x; i < 27 * C3; i += 256) {
         int tap = i / C3, co = i - tap * C3;
@@ -49,7 +52,9 @@ __global__ __launch_bounds__(256) void k_conv3d_first(const float *__restrict__ 
     __syncthreads();
     const float s0 = bn0_s[0], t0 = bn0_t[0];
     const int64_t vol = (int64_t)D * h * w;
-    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t v = idx / G;
+    const int grp = (int)(idx % G);
     const int b = blockIdx.y;
     if (v >= vol) return;
     const int x = (int)(v % w);
@@ -69,27 +74,29 @@ __global__ __launch_bounds__(256) void k_conv3d_first(const float *__restrict__ 
                 if (ok) val = bn_relu(cb[((int64_t)zd * h + zy) * w + zx], s0, t0);
                 a[(kd * 3 + kh) * 3 + kw] = val;
             }
-    float *out = act + ((int64_t)b * vol + v) * C3;
+    float acc[8];
 #pragma unroll
-    for (int c0 = 0; c0 < C3; c0 += 4) {
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
-            const float4 wv = *reinterpret_cast<const float4 *>(&sW[tap * C3 + c0]);
-            acc[0] = fmaf(a[tap], wv.x, acc[0]);
-            acc[1] = fmaf(a[tap], wv.y, acc[1]);
-            acc[2] = fmaf(a[tap], wv.z, acc[2]);
-            acc[3] = fmaf(a[tap], wv.w, acc[3]);
-        }
-        const float4 s = *reinterpret_cast<const float4 *>(bn_s + c0);
-        const float4 t = *reinterpret_cast<const float4 *>(bn_t + c0);
-        float4 o;
-        o.x = bn_relu(acc[0], s.x, t.x);
-        o.y = bn_relu(acc[1], s.y, t.y);
-        o.z = bn_relu(acc[2], s.z, t.z);
-        o.w = bn_relu(acc[3], s.w, t.w);
-        *reinterpret_cast<float4 *>(out + c0) = o;
+    for (int tap = 0; tap < 27; ++tap) {
+        const float4 w0 = *reinterpret_cast<const float4 *>(&sW[tap * C3 + grp * 8]);
+        const float4 w1 = *reinterpret_cast<const float4 *>(&sW[tap * C3 + grp * 8 + 4]);
+        acc[0] = fmaf(a[tap], w0.x, acc[0]);
+        acc[1] = fmaf(a[tap], w0.y, acc[1]);
+        acc[2] = fmaf(a[tap], w0.z, acc[2]);
+        acc[3] = fmaf(a[tap], w0.w, acc[3]);
+        acc[4] = fmaf(a[tap], w1.x, acc[4]);
+        acc[5] = fmaf(a[tap], w1.y, acc[5]);
+        acc[6] = fmaf(a[tap], w1.z, acc[6]);
+        acc[7] = fmaf(a[tap], w1.w, acc[7]);
     }
+    const float4 sa = *reinterpret_cast<const float4 *>(bn_s + grp * 8), sb = *reinterpret_cast<const float4 *>(bn_s + grp * 8 + 4);
+    const float4 ta = *reinterpret_cast<const float4 *>(bn_t + grp * 8), tb = *reinterpret_cast<const float4 *>(bn_t + grp * 8 + 4);
+    float4 *out = reinterpret_cast<float4 *>(act + ((int64_t)b * vol + v) * C3 + grp * 8);
+    out[0] = make_float4(bn_relu(acc[0], sa.x, ta.x), bn_relu(acc[1], sa.y, ta.y), bn_relu(acc[2], sa.z, ta.z),
+                         bn_relu(acc[3], sa.w, ta.w));
+    out[1] = make_float4(bn_relu(acc[4], sb.x, tb.x), bn_relu(acc[5], sb.y, tb.y), bn_relu(acc[6], sb.z, tb.z),
+                         bn_relu(acc[7], sb.w, tb.w));
 }
 
 // =============================================================================================
@@ -408,54 +415,101 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
 }
 
 // =============================================================================================
-// Last layer: act [B,D,h,w,C3] -> cost_out [B,D,h,w] = conv(act) + cost_in   (models.py:137).
-// One thread = one voxel; 27 x C3 fma chain; the weights are [tap][cin] and indexed uniformly, so
-// they come through the scalar cache.
+// Last layer: act [B,D,h,w,C3] -> cost_out [B,D,h,w] = conv(act) + cost_in   (models.py:137), optionally
+// followed in the same kernel by the soft-argmin over D (models.py:142,151-152,167-179) when the tile spans
+// the whole disparity axis (stages 2/3: D = 9).
+// Workgroup = TD x TY x TX output voxels, one thread each; the halo tile is staged in LDS (channels-last,
+// padded voxel stride) with all global loads in flight at once; 27 x C3 fma chain per voxel; the weights
+// [tap][cin] are indexed uniformly (scalar cache).
 // =============================================================================================
-template <int C3>
-__global__ __launch_bounds__(256) void k_conv3d_last(const float *__restrict__ act,
-                                                     const float *__restrict__ wgt,   // [27][C3]
-                                                     const float *__restrict__ skip,
-                                                     float *__restrict__ cost_out, int D, int h, int w)
+template <int C3, int TD, int TY, int TX, bool FUSE>
+struct LastCfg {
+    static constexpr int NOUT = TD * TY * TX;
+    static constexpr int NT = ((NOUT + 63) / 64) * 64;
+    static constexpr int HD = TD + 2, HY = TY + 2, HX = TX + 2;
+    static constexpr int VS = C3 + 4;
+    static constexpr int NVOX = HD * HY * HX;
+    static constexpr int ITEMS = NVOX * (C3 / 4);
+    static constexpr int SITER = (ITEMS + NT - 1) / NT;
+    static constexpr int LDS_FLOATS = NVOX * VS + (FUSE ? NOUT : 0);
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+};
+
+template <int C3, int TD, int TY, int TX, bool FUSE>
+__global__ __launch_bounds__((LastCfg<C3, TD, TY, TX, FUSE>::NT)) void k_conv3d_last(
+    const float *__restrict__ act, const float *__restrict__ wgt,   // [27][C3]
+    const float *__restrict__ skip, float *__restrict__ cost_out,  // may be nullptr when FUSE
+    float *__restrict__ low, float start, int D, int h, int w, int tiles_x, int tiles_y)
 {
-    const int64_t vol = (int64_t)D * h * w;
-    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    using Cfg = LastCfg<C3, TD, TY, TX, FUSE>;
+    constexpr int HY = Cfg::HY, HX = Cfg::HX, VS = Cfg::VS, NT = Cfg::NT, SITER = Cfg::SITER, C4 = C3 / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx_ = tile % tiles_x;
+    tile /= tiles_x;
+    const int ty_ = tile % tiles_y;
+    const int td_ = tile / tiles_y;
     const int b = blockIdx.y;
-    if (v >= vol) return;
-    const int x = (int)(v % w);
-    const int y = (int)((v / w) % h);
-    const int d = (int)(v / ((int64_t)w * h));
+    const int x0 = tx_ * TX, y0 = ty_ * TY, d0 = td_ * TD;
+    const int64_t vol = (int64_t)D * h * w;
     const float *ab = act + (int64_t)b * vol * C3;
-    float acc = 0.0f;
-#pragma unroll 1
-    for (int kd = 0; kd < 3; ++kd) {
-        const int zd = d + kd - 1;
-        if (zd < 0 || zd >= D) continue;
-#pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh) {
-            const int zy = y + kh - 1;
-            if (zy < 0 || zy >= h) continue;
+    {
+        float4 c[SITER];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int zx = x + kw - 1;
-                const int tap = (kd * 3 + kh) * 3 + kw;
-                if (zx >= 0 && zx < w) {
-                    const float4 *p = reinterpret_cast<const float4 *>(ab + (((int64_t)zd * h + zy) * w + zx) * C3);
-                    const float *wt = wgt + tap * C3;
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * NT;
+            const int c4 = it % C4, v = it / C4;
+            const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+            const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            c[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < Cfg::ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w)
+                c[i] = *reinterpret_cast<const float4 *>(ab + (((int64_t)gd * h + gy) * w + gx) * C3 + c4 * 4);
+        }
 #pragma unroll
-                    for (int c4 = 0; c4 < C3 / 4; ++c4) {
-                        const float4 a = p[c4];
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * NT;
+            if (it < Cfg::ITEMS) *reinterpret_cast<float4 *>(&lds[(it / C4) * VS + (it % C4) * 4]) = c[i];
+        }
+    }
+    __syncthreads();
+    const int lx = tid % TX, ly = (tid / TX) % TY, ld = tid / (TX * TY);
+    const int gd = d0 + ld, gy = y0 + ly, gx = x0 + lx;
+    const bool live = tid < Cfg::NOUT && gd < D && gy < h && gx < w;
+    float val = 0.0f;
+    if (tid < Cfg::NOUT) {
+        float acc = 0.0f;
+        const float *base = lds + ((ld * HY + ly) * HX + lx) * VS;
+#pragma unroll 1
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll 1
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float *p = base + ((kd * HY + kh) * HX + kw) * VS;
+                    const float *wt = wgt + ((kd * 3 + kh) * 3 + kw) * C3;
+#pragma unroll
+                    for (int c4 = 0; c4 < C4; ++c4) {
+                        const float4 a = *reinterpret_cast<const float4 *>(p + c4 * 4);
                         acc = fmaf(a.x, wt[c4 * 4 + 0], acc);
                         acc = fmaf(a.y, wt[c4 * 4 + 1], acc);
                         acc = fmaf(a.z, wt[c4 * 4 + 2], acc);
                         acc = fmaf(a.w, wt[c4 * 4 + 3], acc);
                     }
                 }
-            }
+        if (live) {
+            const int64_t o = (int64_t)b * vol + ((int64_t)gd * h + gy) * w + gx;
+            val = acc + skip[o];
+            if (cost_out != nullptr) cost_out[o] = val;
         }
     }
-    const int64_t o = (int64_t)b * vol + v;
-    cost_out[o] = acc + skip[o];
+    if (FUSE) {
+        float *sC = lds + Cfg::NVOX * VS;            // [TD][TY*TX]
+        if (tid < Cfg::NOUT) sC[tid] = val;
+        __syncthreads();
+        if (tid < TY * TX && gy < h && gx < w)       // ld == 0 for these threads: gd = d0 = 0, TD == D
+            low[((int64_t)b * h + gy) * w + gx] = softargmin_pixel(sC + tid, TY * TX, TD, start);
+    }
 }
 
 // =============================================================================================
@@ -503,7 +557,7 @@ void pack_mid_weights(const float *w, int c3, float *out)
 template <int C3>
 static void first_launch(const Stage3d &s, const float *cost, float *act, int B, int D, int h, int w, hipStream_t st)
 {
-    const int64_t vol = (int64_t)D * h * w;
+    const int64_t vol = (int64_t)D * h * w * (C3 / 8);
     dim3 grid((unsigned)((vol + 255) / 256), B), block(256);
     hipLaunchKernelGGL(k_conv3d_first<C3>, grid, block, 0, st, cost, s.layers[0].w, s.layers[0].bn_s,
                        s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act, D, h, w);
@@ -548,6 +602,12 @@ static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out,
                        hipStream_t st)
 {
     using Cfg = Mid8Cfg<TD, TY>;
+    static bool attr_set = false;
+    if (!attr_set && Cfg::LDS_BYTES > 48 * 1024) {
+        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3d_mid8<TD, TY>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr_set = true;
+    }
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
     hipLaunchKernelGGL((k_conv3d_mid8<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w,
@@ -561,7 +621,17 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
                       int w, hipStream_t st)
 {
     switch (s.c3) {
-        case 8: return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+        case 8: {
+            // LWS_MID8_VARIANT=1 selects whole-D tiles (9 rows per wave).  Measured on MI355X (r01): 19.3 us vs
+            // 17.0 us for the 3-deep tile at B=1 256x512 -- one wave per SIMD cannot overlap its own staging with
+            // its MFMAs, three co-resident small workgroups can -- so the 3-deep tile is the default.
+            static const int variant = [] {
+                const char *e = getenv("LWS_MID8_VARIANT");
+                return e ? atoi(e) : 0;
+            }();
+            if (variant == 1 && D >= 9) return mid8_launch<9, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+            return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+        }
         case 16: return mid16_launch<16, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st);
         case 32: {
             // tile/wave-layout variants (LWS_MID16_VARIANT is a development knob; default chosen by measurement)
@@ -580,26 +650,46 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
     }
 }
 
-template <int C3>
-static void last_launch(const Stage3d &s, const float *act, const float *skip, float *out, int B, int D, int h,
-                        int w, hipStream_t st)
+template <int C3, int TD, int TY, int TX, bool FUSE>
+static int last_launch(const Stage3d &s, const float *act, const float *skip, float *cost_out, float *low, float start,
+                       int B, int D, int h, int w, hipStream_t st)
 {
-    const int64_t vol = (int64_t)D * h * w;
-    dim3 grid((unsigned)((vol + 255) / 256), B), block(256);
-    hipLaunchKernelGGL(k_conv3d_last<C3>, grid, block, 0, st, act, s.layers.back().w, skip, out, D, h, w);
+    using Cfg = LastCfg<C3, TD, TY, TX, FUSE>;
+    static bool attr_set = false;
+    if (!attr_set && Cfg::LDS_BYTES > 48 * 1024) {
+        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3d_last<C3, TD, TY, TX, FUSE>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles_x = cdiv(w, TX), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
+    dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
+    hipLaunchKernelGGL((k_conv3d_last<C3, TD, TY, TX, FUSE>), grid, block, Cfg::LDS_BYTES, st, act, s.layers.back().w,
+                       skip, cost_out, low, start, D, h, w, tiles_x, tiles_y);
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
 }
 
 int launch_conv3d_last(const Stage3d &s, const float *act_in, const float *cost_skip, float *cost_out, int B,
                        int D, int h, int w, hipStream_t st)
 {
     switch (s.c3) {
-        case 8: last_launch<8>(s, act_in, cost_skip, cost_out, B, D, h, w, st); break;
-        case 16: last_launch<16>(s, act_in, cost_skip, cost_out, B, D, h, w, st); break;
-        case 32: last_launch<32>(s, act_in, cost_skip, cost_out, B, D, h, w, st); break;
+        case 8: return last_launch<8, 3, 4, 16, false>(s, act_in, cost_skip, cost_out, nullptr, 0.f, B, D, h, w, st);
+        case 16: return last_launch<16, 3, 4, 16, false>(s, act_in, cost_skip, cost_out, nullptr, 0.f, B, D, h, w, st);
+        case 32: return last_launch<32, 3, 4, 16, false>(s, act_in, cost_skip, cost_out, nullptr, 0.f, B, D, h, w, st);
         default: set_error("conv3d: unsupported channel count %d (8, 16, 32)", s.c3); return LWS_ERR_INVALID;
     }
-    LWS_LAUNCH_CHECK();
-    return LWS_OK;
+}
+
+// Last layer + soft-argmin in one launch; available when the tile can span the disparity axis.
+bool conv3d_last_can_fuse(const Stage3d &s, int D) { return D == 9 && (s.c3 == 8 || s.c3 == 16); }
+
+int launch_conv3d_last_softargmin(const Stage3d &s, const float *act_in, const float *cost_skip, float *cost_out,
+                                  float *low, float start, int B, int D, int h, int w, hipStream_t st)
+{
+    if (D == 9 && s.c3 == 8) return last_launch<8, 9, 2, 16, true>(s, act_in, cost_skip, cost_out, low, start, B, D, h, w, st);
+    if (D == 9 && s.c3 == 16) return last_launch<16, 9, 2, 16, true>(s, act_in, cost_skip, cost_out, low, start, B, D, h, w, st);
+    set_error("conv3d_last_softargmin: no fused variant for c3=%d D=%d", s.c3, D);
+    return LWS_ERR_INVALID;
 }
 
 }  // namespace lws

@@ -8,24 +8,55 @@
 
 namespace lws {
 
-// One thread per pixel; the D costs of a pixel are D coalesced plane reads (L1/L2 keep the
-// three passes on chip: a wave's footprint is D x 256 B).  p_k = e_k / S is a correctly
-// rounded division, as in the literal softmax followed by the expectation.
-__global__ __launch_bounds__(256) void k_softargmin(const float *__restrict__ cost, float *__restrict__ low,
-                                                    int64_t plane, int D, float start)
+// One thread per pixel.  The D costs of a pixel are D coalesced plane reads, all issued before the first use
+// (DT = compile-time D keeps them in registers: one memory round trip instead of three dependent passes);
+// DT = 0 is the generic fallback that re-reads through L1.  p_k = e_k / S is a correctly rounded division, as in
+// the literal softmax followed by the expectation.
+template <int DT>
+__global__ __launch_bounds__(64) void k_softargmin(const float *__restrict__ cost, float *__restrict__ low,
+                                                   int64_t plane, int D, float start)
 {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t p = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int b = blockIdx.y;
     if (p >= plane) return;
     const float *c = cost + (int64_t)b * D * plane + p;
-    low[(int64_t)b * plane + p] = softargmin_pixel(c, plane, D, start);
+    float r;
+    if (DT > 0) {
+        float v[DT > 0 ? DT : 1];
+#pragma unroll
+        for (int k = 0; k < DT; ++k) v[k] = c[(int64_t)k * plane];
+        float m = -v[0];
+#pragma unroll
+        for (int k = 1; k < DT; ++k) m = fmaxf(m, -v[k]);
+        float S = 0.0f;
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+            v[k] = lws_expf(-v[k] - m);
+            S = S + v[k];
+        }
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+            float pk = v[k] / S;
+            acc = acc + pk * (start + (float)k);
+        }
+        r = acc;
+    } else {
+        r = softargmin_pixel(c, plane, D, start);
+    }
+    low[(int64_t)b * plane + p] = r;
 }
 
 int launch_softargmin(const float *cost, float *low, int B, int D, int h, int w, float start, hipStream_t st)
 {
     const int64_t plane = (int64_t)h * w;
-    dim3 grid((unsigned)((plane + 255) / 256), B), block(256);
-    hipLaunchKernelGGL(k_softargmin, grid, block, 0, st, cost, low, plane, D, start);
+    dim3 grid((unsigned)((plane + 63) / 64), B), block(64);   // 64-thread blocks: the stage-1 map has only h*w = 2048 pixels
+    switch (D) {
+        case 9: hipLaunchKernelGGL(k_softargmin<9>, grid, block, 0, st, cost, low, plane, D, start); break;
+        case 24: hipLaunchKernelGGL(k_softargmin<24>, grid, block, 0, st, cost, low, plane, D, start); break;
+        case 32: hipLaunchKernelGGL(k_softargmin<32>, grid, block, 0, st, cost, low, plane, D, start); break;
+        default: hipLaunchKernelGGL(k_softargmin<0>, grid, block, 0, st, cost, low, plane, D, start); break;
+    }
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
