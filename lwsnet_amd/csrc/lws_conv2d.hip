@@ -26,55 +26,72 @@ __device__ __forceinline__ float bn_relu2(float x, float s, float t) { return fm
 __device__ __forceinline__ float f4c(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
 // =============================================================================================
-// Feature extractor: direct 3x3 convolution on NCHW planes, one thread = one output pixel x CPT output
-// channels (blockIdx.z enumerates (image, output-channel group) so that the small 1/4 and 1/8 resolution
-// layers still fill the chip).  Weights are stored [tap][cin][cout] and indexed wave-uniformly (scalar loads).
+// Feature extractor: 3x3 convolution / stride-2 transposed convolution on NCHW planes (3..16 channels).
+// Workgroup = an 8 x 8 output tile of one image, ALL output channels: the input region the tile needs (all CIN
+// planes, zero outside the image) is staged once in LDS with every global load in flight; wave w then computes
+// output channels [w*COUT/4, (w+1)*COUT/4) for the 64 pixels (one pixel per lane), so the weights
+// ([tap][cin][cout]) are wave-uniform and come through the scalar cache.
 // Epilogue: BatchNorm (optional) -> + residual (optional) -> ReLU (optional).
 // =============================================================================================
-template <int CIN, int CPT, bool TRANSPOSED>
-__global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ in, const float *__restrict__ wgt,   // [tap][cin][COUT]
+template <int CIN, int COUT, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ in, const float *__restrict__ wgt,
                                                      const float *__restrict__ bn_s, const float *__restrict__ bn_t,
-                                                     const float *__restrict__ res, float *__restrict__ out, int COUT,
-                                                     int H, int W, int Ho, int Wo, int stride, int pad, int dil,
-                                                     int relu)
+                                                     const float *__restrict__ res, float *__restrict__ out, int H,
+                                                     int W, int Ho, int Wo, int stride, int pad, int dil, int relu,
+                                                     int RH, int RW, int RWp)
 {
-    const int groups = COUT / CPT;
-    const int b = blockIdx.z / groups, co0 = (blockIdx.z % groups) * CPT;   // wave-uniform: weights go through the scalar cache
-    const int ox = blockIdx.x * 64 + threadIdx.x, oy = blockIdx.y * 4 + threadIdx.y;
-    if (ox >= Wo || oy >= Ho) return;
-    const int64_t plane = (int64_t)H * W, oplane = (int64_t)Ho * Wo;
+    constexpr int CPT = COUT / 4;
+    extern __shared__ float sIn[];   // [CIN][RH][RWp]
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x, tx = tid & 7, ty = (tid >> 3) & 7;
+    const int co0 = (tid >> 6) * CPT;                       // wave-uniform
+    const int ox0 = blockIdx.x * 8, oy0 = blockIdx.y * 8;
+    const int ry0 = TRANSPOSED ? ((oy0 - 1) >> 1) : oy0 * stride - pad;
+    const int rx0 = TRANSPOSED ? ((ox0 - 1) >> 1) : ox0 * stride - pad;
+    const int plane = H * W, oplane = Ho * Wo;
     const float *inb = in + (int64_t)b * CIN * plane;
+    const int rsz = RH * RW, total = CIN * rsz;
+#pragma unroll 8
+    for (int i = tid; i < total; i += 256) {
+        const int ci = i / rsz, r = i - ci * rsz;
+        const int ry = r / RW, rx = r - ry * RW;
+        const int gy = ry0 + ry, gx = rx0 + rx;
+        const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const float v = inb[ok ? ci * plane + gy * W + gx : 0];   // unconditional load, masked after
+        sIn[(ci * RH + ry) * RWp + rx] = ok ? v : 0.0f;
+    }
+    __syncthreads();
+    const int ox = ox0 + tx, oy = oy0 + ty;
+    if (ox >= Wo || oy >= Ho) return;
     float acc[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) acc[c] = 0.0f;
-    // runtime tap loop: one iteration keeps CIN loads in flight and CPT accumulators live (a fully unrolled
-    // 9*CIN*CPT body makes hipcc hoist every load and spill)
-#pragma unroll 1
+    const int cstride = RH * RWp;
+#pragma unroll 3
     for (int tap = 0; tap < 9; ++tap) {
         const int kh = tap / 3, kw = tap - kh * 3;
-        int iy, ix;
-        bool ok;
+        int ly, lx;
+        bool ok = true;
         if (TRANSPOSED) {          // oy = 2*iy - 1 + kh  (k3, s2, p1, output_padding 1)
-            const int ty = oy + 1 - kh, tx = ox + 1 - kw;
-            iy = ty >> 1;
-            ix = tx >> 1;
-            ok = ty >= 0 && !(ty & 1) && iy < H && tx >= 0 && !(tx & 1) && ix < W;
+            const int t_y = oy + 1 - kh, t_x = ox + 1 - kw;
+            ok = t_y >= 0 && !(t_y & 1) && (t_y >> 1) < H && t_x >= 0 && !(t_x & 1) && (t_x >> 1) < W;
+            ly = (t_y >> 1) - ry0;
+            lx = (t_x >> 1) - rx0;
         } else {
-            iy = oy * stride - pad + kh * dil;
-            ix = ox * stride - pad + kw * dil;
-            ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            ly = ty * stride + kh * dil;
+            lx = tx * stride + kw * dil;
         }
-        const float *p = inb + (int64_t)(ok ? iy : 0) * W + (ok ? ix : 0);
-        const float *w = wgt + (int64_t)tap * CIN * COUT + co0;
+        const float *p = sIn + (ok ? ly * RWp + lx : 0);
+        const float *w = wgt + tap * CIN * COUT + co0;
         float v[CIN];
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) v[ci] = ok ? p[(int64_t)ci * plane] : 0.0f;
+        for (int ci = 0; ci < CIN; ++ci) v[ci] = ok ? p[ci * cstride] : 0.0f;
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
             for (int c = 0; c < CPT; ++c) acc[c] = fmaf(v[ci], w[ci * COUT + c], acc[c]);
     }
-    const int64_t o = ((int64_t)b * COUT + co0) * oplane + (int64_t)oy * Wo + ox;
+    const int64_t o = ((int64_t)b * COUT + co0) * oplane + oy * Wo + ox;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         float v = acc[c];
@@ -85,13 +102,18 @@ __global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ i
     }
 }
 
-template <int CIN, int CPT, bool TR>
-static void conv2d_launch(const Conv2dLayer &l, const float *in, const float *res, float *out, int N, int H, int W,
-                          int Ho, int Wo, hipStream_t st)
+template <int CIN, int COUT, bool TR>
+static int conv2d_launch(const Conv2dLayer &l, const float *in, const float *res, float *out, int N, int H, int W,
+                         int Ho, int Wo, hipStream_t st)
 {
-    dim3 grid(cdiv(Wo, 64), cdiv(Ho, 4), N * (l.cout / CPT)), block(64, 4);
-    hipLaunchKernelGGL((k_conv2d_nchw<CIN, CPT, TR>), grid, block, 0, st, in, l.w, l.bn_s, l.bn_t, res, out, l.cout, H,
-                       W, Ho, Wo, l.stride, l.pad, l.dil, l.relu ? 1 : 0);
+    const int RH = TR ? 6 : 7 * l.stride + 2 * l.dil + 1, RW = RH;
+    const int RWp = RW | 1;                                       // odd row stride
+    const size_t lds = (size_t)CIN * RH * RWp * sizeof(float);
+    dim3 grid(cdiv(Wo, 8), cdiv(Ho, 8), N), block(256);
+    hipLaunchKernelGGL((k_conv2d_nchw<CIN, COUT, TR>), grid, block, lds, st, in, l.w, l.bn_s, l.bn_t, res, out, H, W, Ho,
+                       Wo, l.stride, l.pad, l.dil, l.relu ? 1 : 0, RH, RW, RWp);
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
 }
 
 // N images [N,cin,H,W] -> [N,cout,Ho,Wo]
@@ -106,17 +128,11 @@ int launch_conv2d_nchw(const Conv2dLayer &l, const float *in, const float *res, 
         Ho = (H + 2 * l.pad - 2 * l.dil - 1) / l.stride + 1;
         Wo = (W + 2 * l.pad - 2 * l.dil - 1) / l.stride + 1;
     }
-    // output channels per thread: fewer at low resolution so that the grid still covers the chip
-    const int64_t px = (int64_t)N * Ho * Wo;
-    const int cpt = l.cout <= 4 ? l.cout : (px >= 49152 ? (l.cout >= 8 ? 8 : 4) : 4);
-#define LWS_C2D(CI, CP)                                                                               \
-    if (l.cin == CI && cpt == CP) {                                                                   \
-        if (l.transposed) conv2d_launch<CI, CP, true>(l, in, res, out, N, H, W, Ho, Wo, st);          \
-        else conv2d_launch<CI, CP, false>(l, in, res, out, N, H, W, Ho, Wo, st);                      \
-        LWS_LAUNCH_CHECK();                                                                           \
-        return LWS_OK;                                                                                \
-    }
-    LWS_C2D(3, 4) LWS_C2D(4, 8) LWS_C2D(4, 4) LWS_C2D(8, 4) LWS_C2D(8, 8) LWS_C2D(16, 4) LWS_C2D(16, 8)
+#define LWS_C2D(CI, CO, TR)                                   \
+    if (l.cin == CI && l.cout == CO && l.transposed == TR)    \
+        return conv2d_launch<CI, CO, TR>(l, in, res, out, N, H, W, Ho, Wo, st);
+    LWS_C2D(3, 4, false) LWS_C2D(4, 8, false) LWS_C2D(8, 4, false) LWS_C2D(8, 16, false) LWS_C2D(16, 16, false)
+    LWS_C2D(16, 16, true) LWS_C2D(16, 8, true) LWS_C2D(8, 8, false)
 #undef LWS_C2D
     set_error("conv2d_nchw: unsupported layer cin=%d cout=%d", l.cin, l.cout);
     return LWS_ERR_INVALID;
@@ -150,7 +166,8 @@ __global__ __launch_bounds__(256) void k_ref_first(const float *__restrict__ in,
         const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci) {
-            const float v = ok ? inb[(int64_t)ci * plane + (int64_t)iy * W + ix] : 0.0f;
+            const float ld = inb[ok ? (int64_t)ci * plane + (int64_t)iy * W + ix : 0];
+            const float v = ok ? ld : 0.0f;
             const float4 w0 = *reinterpret_cast<const float4 *>(&sW[(tap * CIN + ci) * 32 + grp * 8]);
             const float4 w1 = *reinterpret_cast<const float4 *>(&sW[(tap * CIN + ci) * 32 + grp * 8 + 4]);
             acc[0] = fmaf(v, w0.x, acc[0]);
@@ -175,15 +192,20 @@ __global__ __launch_bounds__(256) void k_ref_first(const float *__restrict__ in,
 // is (RT_Y+2) x (RT_X+2) pixels for every dilation (1.56x read amplification instead of 9 re-reads), and every
 // pixel it touches is a whole 128-byte line of the channels-last map.
 // =============================================================================================
-constexpr int RT_Y = 8, RT_X = 16;                // tile: 8 rows of 16 pixels (one MFMA N-tile per row)
+constexpr int RT_Y = 8, RT_X = 16;                // k_ref_dws tile: 8 rows of 16 pixels (one MFMA N-tile per row)
 constexpr int RH_Y = RT_Y + 2, RH_X = RT_X + 2;   // halo tile
-constexpr int RVS = 36;                           // LDS pixel stride in dwords (32 channels + 4 pad)
+constexpr int RVS = 32;                           // LDS pixel stride in dwords: 32 channels, no padding ...
+
+// ... instead the eight 16-byte channel groups of pixel p are XOR-swizzled with (p & 7): ds_read_b128 of 8
+// consecutive pixels at the same group then covers all 64 banks, and the LDS image stays 128 B per pixel
+// (k_ref_dws fits 4 workgroups per CU, k_ref_conv64 5).
+__device__ __forceinline__ int swz(int p, int grp) { return p * RVS + ((grp ^ (p & 7)) << 2); }
 
 struct RefTile {
     int b, Y0, X0;
 };
 
-__device__ __forceinline__ RefTile ref_tile(int dil, int nbx, int nby)
+__device__ __forceinline__ RefTile ref_tile(int dil, int nbx, int nby, int tile_rows = RT_Y)
 {
     int bid = blockIdx.x;
     const int d2 = dil * dil;
@@ -194,7 +216,7 @@ __device__ __forceinline__ RefTile ref_tile(int dil, int nbx, int nby)
     const int by = bid % nby;
     RefTile t;
     t.b = bid / nby;
-    t.Y0 = by * RT_Y * dil + phase / dil;
+    t.Y0 = by * tile_rows * dil + phase / dil;
     t.X0 = bx * RT_X * dil + phase % dil;
     return t;
 }
@@ -208,77 +230,82 @@ __device__ __forceinline__ RefTile ref_tile(int dil, int nbx, int nby)
 //   3. pointwise on fp32 MFMA: Out^T[cout, pixel] = W[cout, cin] * X[cin, pixel], K = 32 = 8 MFMAs per tile;
 //   4. store the raw result (the next block applies its own BatchNorm while staging).
 // =============================================================================================
+// LDS images of k_ref_dws are planar by 4-channel group: sA[c4][halo pixel] and sB[4q+g][tile pixel] as float4, so
+// that every depthwise tap and every transposed write is base + compile-time offset (no per-tap address VALU);
+// plane strides of 186 / 130 float4 put the 8 planes of one pixel 40 / 8 dwords apart mod 64: conflict-free b128.
+constexpr int DWS_SA = 186, DWS_SB = 130;
+
 __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, const float *__restrict__ bn_s,
                                                  const float *__restrict__ bn_t, const float *__restrict__ dw,   // [tap][32]
                                                  const float4 *__restrict__ pwpk,                              // [q][mt][lane]
                                                  float *__restrict__ out, int H, int W, int dil, int nbx, int nby)
 {
-    __shared__ __attribute__((aligned(16))) float sA[RH_Y * RH_X * RVS];
-    __shared__ __attribute__((aligned(16))) float sB[RT_Y * RT_X * RVS];
+    __shared__ float4 sA[8 * DWS_SA];
+    __shared__ float4 sB[8 * DWS_SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RefTile t = ref_tile(dil, nbx, nby);
     const float *inb = in + (int64_t)t.b * H * W * 32;
 
-    // pointwise A fragments (4 float4) and this thread's depthwise weights (9 float4: c4 = tid % 8 is fixed)
+    const int c4 = tid & 7;
+    const float4 s4 = *reinterpret_cast<const float4 *>(bn_s + c4 * 4);
+    const float4 t4 = *reinterpret_cast<const float4 *>(bn_t + c4 * 4);
+
+    // 1. stage: item = (halo pixel hp, 4-channel group c4); hp = (tid >> 3) + 32 i.  Unconditional clamped loads first.
+    constexpr int NPX = RH_Y * RH_X, SITER = (NPX * 8 + 255) / 256;
+    float4 c[SITER];
+    bool okv[SITER];
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int hp = (tid >> 3) + 32 * i;
+        const int hy = hp / RH_X, hx = hp - hy * RH_X;
+        const int gy = t.Y0 + (hy - 1) * dil, gx = t.X0 + (hx - 1) * dil;
+        okv[i] = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int off = okv[i] ? (gy * W + gx) * 32 + c4 * 4 : 0;      // one image < 2^31 floats
+        c[i] = *reinterpret_cast<const float4 *>(inb + off);
+    }
+    // pointwise A fragments and this thread's depthwise weights (its channel group is fixed)
     float4 aw[2][2];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) aw[q][mt] = pwpk[(q * 2 + mt) * 64 + lane];
-    const int c4 = tid & 7;
     float4 wd[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) wd[tap] = *reinterpret_cast<const float4 *>(dw + tap * 32 + c4 * 4);
-    const float4 s4 = *reinterpret_cast<const float4 *>(bn_s + c4 * 4);
-    const float4 t4 = *reinterpret_cast<const float4 *>(bn_t + c4 * 4);
-
-    // 1. stage: item = (halo pixel, 4-channel group); 180 * 8 = 1440 items
-    constexpr int ITEMS = RH_Y * RH_X * 8, SITER = (ITEMS + 255) / 256;
-    float4 c[SITER];
 #pragma unroll
     for (int i = 0; i < SITER; ++i) {
-        const int it = tid + i * 256;
-        const int hp = it >> 3;
-        const int hy = hp / RH_X, hx = hp % RH_X;
-        const int gy = t.Y0 + (hy - 1) * dil, gx = t.X0 + (hx - 1) * dil;
-        c[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (it < ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const float4 v = *reinterpret_cast<const float4 *>(inb + ((int64_t)gy * W + gx) * 32 + c4 * 4);
-            c[i] = make_float4(bn_relu2(v.x, s4.x, t4.x), bn_relu2(v.y, s4.y, t4.y), bn_relu2(v.z, s4.z, t4.z),
-                               bn_relu2(v.w, s4.w, t4.w));
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < SITER; ++i) {
-        const int it = tid + i * 256;
-        if (it < ITEMS) *reinterpret_cast<float4 *>(&sA[(it >> 3) * RVS + c4 * 4]) = c[i];
+        const int hp = (tid >> 3) + 32 * i;
+        float4 v = make_float4(bn_relu2(c[i].x, s4.x, t4.x), bn_relu2(c[i].y, s4.y, t4.y), bn_relu2(c[i].z, s4.z, t4.z),
+                               bn_relu2(c[i].w, s4.w, t4.w));
+        if (!okv[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hp < NPX) sA[c4 * DWS_SA + hp] = v;
     }
     __syncthreads();
 
-    // 2. depthwise: 128 pixels x 8 groups = 1024 items, 4 per thread
+    // 2. depthwise: tile pixel p = (tid >> 3) + 32 i  ->  row (tid >> 7) + 2 i, column (tid >> 3) & 15
     {
         const int q = c4 >> 2, a_ = c4 & 3;
+        const float4 *src = sA + c4 * DWS_SA + (tid >> 7) * RH_X + ((tid >> 3) & 15);
+        float *dst = reinterpret_cast<float *>(sB + (4 * q) * DWS_SB + (tid >> 3)) + a_;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int p = (tid >> 3) + i * 32;
-            const int pi = p / RT_X, pj = p % RT_X;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const float4 a = *reinterpret_cast<const float4 *>(&sA[((pi + kh) * RH_X + pj + kw) * RVS + c4 * 4]);
+                    const float4 a = src[(2 * i + kh) * RH_X + kw];
                     const float4 w = wd[kh * 3 + kw];
                     acc.x = fmaf(a.x, w.x, acc.x);
                     acc.y = fmaf(a.y, w.y, acc.y);
                     acc.z = fmaf(a.z, w.z, acc.z);
                     acc.w = fmaf(a.w, w.w, acc.w);
                 }
-            float *d = &sB[p * RVS + 16 * q + a_];      // channel 16q + 4a_ + e -> dword 16q + 4e + a_
-            d[0] = acc.x;
-            d[4] = acc.y;
-            d[8] = acc.z;
-            d[12] = acc.w;
+            // channel 16q + 4a_ + e -> plane 4q + e, element a_ (the 4x4 transpose the MFMA B operand wants)
+            dst[(0 * DWS_SB + 32 * i) * 4] = acc.x;
+            dst[(1 * DWS_SB + 32 * i) * 4] = acc.y;
+            dst[(2 * DWS_SB + 32 * i) * 4] = acc.z;
+            dst[(3 * DWS_SB + 32 * i) * 4] = acc.w;
         }
     }
     __syncthreads();
@@ -294,8 +321,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-            bv[r][q] = *reinterpret_cast<const float4 *>(&sB[((2 * wave + r) * RT_X + n) * RVS + 16 * q + 4 * g]);
+        for (int q = 0; q < 2; ++q) bv[r][q] = sB[(4 * q + g) * DWS_SB + (2 * wave + r) * RT_X + n];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -313,7 +339,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
     for (int r = 0; r < 2; ++r) {
         const int gy = t.Y0 + (2 * wave + r) * dil;
         if (gy < H && gx < W) {
-            float *o = outb + ((int64_t)gy * W + gx) * 32;
+            float *o = outb + (gy * W + gx) * 32;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
                 *reinterpret_cast<float4 *>(o + mt * 16 + 4 * g) =
@@ -328,51 +354,55 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
 // channels-last maps are staged side by side.  fp32-MFMA implicit GEMM, K = 9 taps x 64 channels = 144 MFMAs per
 // accumulator; weights streamed from L2 in fragment order one step ahead (same scheme as k_conv3d_mid16).
 // =============================================================================================
+template <int TY>   // tile rows (4 waves: TY/4 rows each)
 __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ inL, const float *__restrict__ inD,
                                                     const float *__restrict__ bn_s, const float *__restrict__ bn_t,   // [64]
                                                     const float4 *__restrict__ wpk,   // [tap][qq][mt][lane]
                                                     float *__restrict__ out, int H, int W, int dil, int nbx, int nby)
 {
-    __shared__ __attribute__((aligned(16))) float sA[2 * RH_Y * RH_X * RVS];
+    constexpr int HY = TY + 2, NPX = HY * RH_X, RW = TY / 4;
+    __shared__ __attribute__((aligned(16))) float sA[2 * NPX * RVS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const RefTile t = ref_tile(dil, nbx, nby);
+    const RefTile t = ref_tile(dil, nbx, nby, TY);
     const int n = lane & 15, g = lane >> 4;
 
-    // stage: item = (tensor, halo pixel, 16-channel group): 2 * 180 * 2 = 720 items of 64 bytes
-    constexpr int NPX = RH_Y * RH_X, ITEMS = 2 * NPX * 2, SITER = (ITEMS + 255) / 256;
+    // stage: item = (tensor, halo pixel, 16-channel group) = 64 bytes
+    constexpr int ITEMS = 2 * NPX * 2, SITER = (ITEMS + 255) / 256;
     {
         float4 c[SITER][4];
+        bool okv[SITER];
 #pragma unroll
-        for (int i = 0; i < SITER; ++i) {
+        for (int i = 0; i < SITER; ++i) {          // unconditional, clamped loads first (see k_ref_dws)
             const int it = tid + i * 256;
             const int q = it & 1, hp = (it >> 1) % NPX, ten = (it >> 1) / NPX;
             const int hy = hp / RH_X, hx = hp % RH_X;
             const int gy = t.Y0 + (hy - 1) * dil, gx = t.X0 + (hx - 1) * dil;
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            c[i][0] = c[i][1] = c[i][2] = c[i][3] = z;
-            if (it < ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const float *base = (ten == 0 ? inL : inD) + (int64_t)t.b * H * W * 32;
-                const float4 *src = reinterpret_cast<const float4 *>(base + ((int64_t)gy * W + gx) * 32 + q * 16);
-                const float4 *sp = reinterpret_cast<const float4 *>(bn_s + ten * 32 + q * 16);
-                const float4 *tp = reinterpret_cast<const float4 *>(bn_t + ten * 32 + q * 16);
+            okv[i] = it < ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float *base = (ten == 1 && it < ITEMS ? inD : inL) + (int64_t)t.b * H * W * 32;
+            const float4 *src = reinterpret_cast<const float4 *>(base + (okv[i] ? ((int64_t)gy * W + gx) * 32 + q * 16 : 0));
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float4 v = src[k], s = sp[k], tt = tp[k];
-                    c[i][k] = make_float4(bn_relu2(v.x, s.x, tt.x), bn_relu2(v.y, s.y, tt.y), bn_relu2(v.z, s.z, tt.z),
-                                          bn_relu2(v.w, s.w, tt.w));
-                }
-            }
+            for (int k = 0; k < 4; ++k) c[i][k] = src[k];
         }
 #pragma unroll
         for (int i = 0; i < SITER; ++i) {
             const int it = tid + i * 256;
             if (it < ITEMS) {
                 const int q = it & 1, hp = (it >> 1) % NPX, ten = (it >> 1) / NPX;
-                float4 *dst = reinterpret_cast<float4 *>(&sA[(ten * NPX + hp) * RVS + q * 16]);
-                dst[0] = make_float4(c[i][0].x, c[i][1].x, c[i][2].x, c[i][3].x);
-                dst[1] = make_float4(c[i][0].y, c[i][1].y, c[i][2].y, c[i][3].y);
-                dst[2] = make_float4(c[i][0].z, c[i][1].z, c[i][2].z, c[i][3].z);
-                dst[3] = make_float4(c[i][0].w, c[i][1].w, c[i][2].w, c[i][3].w);
+                const float4 *sp = reinterpret_cast<const float4 *>(bn_s + ten * 32 + q * 16);
+                const float4 *tp = reinterpret_cast<const float4 *>(bn_t + ten * 32 + q * 16);
+                float4 a[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 v = c[i][k], sc = sp[k], tt = tp[k];
+                    a[k] = make_float4(bn_relu2(v.x, sc.x, tt.x), bn_relu2(v.y, sc.y, tt.y), bn_relu2(v.z, sc.z, tt.z),
+                                       bn_relu2(v.w, sc.w, tt.w));
+                    if (!okv[i]) a[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                float *img = sA + ten * NPX * RVS;      // 4x4 transpose inside the 16-channel group, swizzled groups
+                *reinterpret_cast<float4 *>(&img[swz(hp, 4 * q + 0)]) = make_float4(a[0].x, a[1].x, a[2].x, a[3].x);
+                *reinterpret_cast<float4 *>(&img[swz(hp, 4 * q + 1)]) = make_float4(a[0].y, a[1].y, a[2].y, a[3].y);
+                *reinterpret_cast<float4 *>(&img[swz(hp, 4 * q + 2)]) = make_float4(a[0].z, a[1].z, a[2].z, a[3].z);
+                *reinterpret_cast<float4 *>(&img[swz(hp, 4 * q + 3)]) = make_float4(a[0].w, a[1].w, a[2].w, a[3].w);
             }
         }
     }
@@ -384,19 +414,19 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
         for (int mt = 0; mt < 2; ++mt) w_cur[qq][mt] = wp[(qq * 2 + mt) * 64];
     __syncthreads();
 
-    floatx4 acc[2][2];
-    int rbase[2];
+    floatx4 acc[RW][2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < RW; ++r)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
-        rbase[r] = ((2 * wave + r) * RH_X + n) * RVS + 4 * g;
-    }
     // step = (tap, qq): qq = 2*tensor + 16-channel group -> input channels 16*qq .. 16*qq+15 of the concat
-    auto step_off = [](int tap, int qq) { return ((qq >> 1) * NPX + (tap / 3) * RH_X + tap % 3) * RVS + (qq & 1) * 16; };
-    float4 b_cur[2], b_nxt[2];
+    auto frag = [&](int r, int tap, int qq) {
+        const int hp = (RW * wave + r + tap / 3) * RH_X + n + tap % 3;
+        return *reinterpret_cast<const float4 *>(&sA[(qq >> 1) * NPX * RVS + swz(hp, 4 * (qq & 1) + g)]);
+    };
+    float4 b_cur[RW], b_nxt[RW];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) b_cur[r] = *reinterpret_cast<const float4 *>(&sA[rbase[r] + step_off(0, 0)]);
+    for (int r = 0; r < RW; ++r) b_cur[r] = frag(r, 0, 0);
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
         const int tn = tap < 8 ? tap + 1 : 8;
@@ -406,20 +436,19 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
             for (int mt = 0; mt < 2; ++mt) w_nxt[qq][mt] = wp[((tn * 4 + qq) * 2 + mt) * 64];
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            const int off_n = qq < 3 ? step_off(tap, qq + 1) : step_off(tn, 0);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) b_nxt[r] = *reinterpret_cast<const float4 *>(&sA[rbase[r] + off_n]);
+            for (int r = 0; r < RW; ++r) b_nxt[r] = qq < 3 ? frag(r, tap, qq + 1) : frag(r, tn, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+                for (int r = 0; r < RW; ++r)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
                         acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(w_cur[qq][mt], j), f4c(b_cur[r], j), acc[r][mt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) b_cur[r] = b_nxt[r];
+            for (int r = 0; r < RW; ++r) b_cur[r] = b_nxt[r];
         }
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
@@ -429,8 +458,8 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
     float *outb = out + (int64_t)t.b * H * W * 32;
     const int gx = t.X0 + n * dil;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int gy = t.Y0 + (2 * wave + r) * dil;
+    for (int r = 0; r < RW; ++r) {
+        const int gy = t.Y0 + (RW * wave + r) * dil;
         if (gy < H && gx < W) {
             float *o = outb + ((int64_t)gy * W + gx) * 32;
 #pragma unroll
@@ -505,11 +534,13 @@ int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, i
 int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, float *out, int B, int H, int W,
                       hipStream_t st)
 {
+    // 4-row tiles: 27 KB of LDS per workgroup -> 5 workgroups (5 waves per SIMD) share each CU's MFMA pipes
+    constexpr int TY = 4;
     const int dil = 8;
-    const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, RT_Y * dil);
+    const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, TY * dil);
     dim3 grid(nbx * nby * dil * dil * B), block(256);
-    hipLaunchKernelGGL(k_ref_conv64, grid, block, 0, st, inL, inD, l.bn_s, l.bn_t, reinterpret_cast<const float4 *>(l.w),
-                       out, H, W, dil, nbx, nby);
+    hipLaunchKernelGGL(k_ref_conv64<TY>, grid, block, 0, st, inL, inD, l.bn_s, l.bn_t,
+                       reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }

@@ -70,9 +70,8 @@ __global__ __launch_bounds__(256) void k_conv3d_first(const float *__restrict__ 
             for (int kw = 0; kw < 3; ++kw) {
                 int zd = d + kd - 1, zy = y + kh - 1, zx = x + kw - 1;
                 bool ok = zd >= 0 && zd < D && zy >= 0 && zy < h && zx >= 0 && zx < w;
-                float val = 0.0f;
-                if (ok) val = bn_relu(cb[((int64_t)zd * h + zy) * w + zx], s0, t0);
-                a[(kd * 3 + kh) * 3 + kw] = val;
+                const float ld = cb[ok ? ((int64_t)zd * h + zy) * w + zx : 0];
+                a[(kd * 3 + kh) * 3 + kw] = ok ? bn_relu(ld, s0, t0) : 0.0f;
             }
     float acc[8];
 #pragma unroll
@@ -185,15 +184,14 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
             const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
             const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
             const bool ok = it < Cfg::ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            // unconditional loads (padding / surplus items read voxel 0 and are zeroed below): no branch per load
+            const float4 *src = reinterpret_cast<const float4 *>(inb + (ok ? (((int64_t)gd * h + gy) * w + gx) * C3 + q * 16 : 0));
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            c[i][0] = c[i][1] = c[i][2] = c[i][3] = z;
-            if (ok) {
-                const float4 *src = reinterpret_cast<const float4 *>(inb + (((int64_t)gd * h + gy) * w + gx) * C3 + q * 16);
-                c[i][0] = src[0];
-                c[i][1] = src[1];
-                c[i][2] = src[2];
-                c[i][3] = src[3];
-            }
+            c[i][0] = src[0];
+            c[i][1] = src[1];
+            c[i][2] = src[2];
+            c[i][3] = src[3];
+            if (!ok) c[i][0] = c[i][1] = c[i][2] = c[i][3] = z;
         }
 #pragma unroll
         for (int i = 0; i < SITER; ++i) {
@@ -209,13 +207,14 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
         }
     }
 
-    // weights of this wave: [tap][q][mt][lane] float4, mt in [wm*MTW, (wm+1)*MTW)
+    // weights of this wave: [tap][q][mt][lane] float4, mt in [wm*MTW, (wm+1)*MTW); the packed array holds one
+    // extra all-zero tap so that the "next tap" prefetch never needs a bounds check
     const float4 *wp = wpk + (wm * MTW) * 64 + lane;
-    float4 w_cur[Q][MTW], w_nxt[Q][MTW];
+    float4 wbuf[3][Q][MTW];                         // ring over kw: tap kw of the current (kd,kh) lives in wbuf[kw]
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) w_cur[q][mt] = wp[(q * MT + mt) * 64];
+        for (int mt = 0; mt < MTW; ++mt) wbuf[0][q][mt] = wp[(q * MT + mt) * 64];
     __syncthreads();
 
     floatx4 acc[RW][MTW];
@@ -225,52 +224,74 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
         for (int mt = 0; mt < MTW; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
     // per-row LDS base of this lane: voxel (rd, ry, n) of the halo tile, channel quad g
-    int rbase[RW];
+    const float *rptr[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         const int row = wr * RW + r;
         const int rd = row / TY, ry = row % TY;
-        rbase[r] = ((rd * HY + ry) * HX + n) * VS + 4 * g;
+        rptr[r] = lds + ((rd * HY + ry) * HX + n) * VS + 4 * g;
     }
 
-    // Software pipeline: the weights of tap t+1 and the activation fragments of step s+1 are requested
-    // BEFORE the MFMAs of step s; the sched_barriers keep hipcc from sinking the loads to their first use
-    // (which would expose the full L2 / LDS latency at one wave per SIMD).
-    float4 b_cur[RW], b_nxt[RW];
+    // Software pipeline without copies: 3 taps (kw) x Q channel groups = 3Q steps per (kd,kh) iteration; activation
+    // fragments ping-pong between bbuf[0/1] by step parity (3Q even), weights rotate through wbuf[kw].  The prefetch
+    // of step s+1 / tap t+1 is issued in small fenced slices BETWEEN the four 6-MFMA groups of step s, so that every
+    // ds_read / global_load issues under a running MFMA instead of stalling the matrix pipe at step boundaries.
+    // (Q == 1, i.e. C3 == 16, has an odd number of steps per iteration: it copies bbuf[1] -> bbuf[0] instead.)
+    float4 bbuf[2][RW];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) b_cur[r] = *reinterpret_cast<const float4 *>(lds + rbase[r]);
+    for (int r = 0; r < RW; ++r) bbuf[0][r] = *reinterpret_cast<const float4 *>(rptr[r]);
 
 #pragma unroll 1
-    for (int tap = 0; tap < 27; ++tap) {
-        const int tn = tap < 26 ? tap + 1 : 26;                      // next tap (clamped: last prefetch is unused)
-        const int toff = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * VS;
-        const int toff_n = (((tn / 9) * HY + (tn / 3) % 3) * HX + tn % 3) * VS;
+    for (int kdh = 0; kdh < 9; ++kdh) {
+        const int kd = kdh / 3, kh = kdh - kd * 3;
+        const int base = (kd * HY + kh) * HX * VS;
+        // first fragment offset of the NEXT (kd,kh) iteration (clamped for the last one: the prefetch is unused)
+        const int kn = kdh < 8 ? kdh + 1 : 8;
+        const int base_n = ((kn / 3) * HY + (kn % 3)) * HX * VS;
+        const float4 *wtap = wp + (size_t)(kdh * 3) * Q * MT * 64;
 #pragma unroll
-        for (int q = 0; q < Q; ++q)
+        for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) w_nxt[q][mt] = wp[((tn * Q + q) * MT + mt) * 64];
+            for (int q = 0; q < Q; ++q) {
+                const int s = kw * Q + q;                      // step inside the iteration (compile time)
+                const int cur = (Q % 2 == 0) ? (s & 1) : 0;
+                float4 *bc = bbuf[cur], *bn = bbuf[cur ^ 1];
+                // where the next step reads its activation fragments
+                const bool same_tap = q + 1 < Q;
+                const int off_n = same_tap ? base + kw * VS + (q + 1) * 16 : (kw < 2 ? base + (kw + 1) * VS : base_n);
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int off_n = (q + 1 < Q) ? toff + (q + 1) * 16 : toff_n;
+                for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int r = 0; r < RW; ++r) b_nxt[r] = *reinterpret_cast<const float4 *>(lds + rbase[r] + off_n);
-            __builtin_amdgcn_sched_barrier(0);
-            // j outermost: consecutive MFMAs hit RW*MTW different accumulators (40-cycle dependent latency)
+                    for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                        for (int mt = 0; mt < MTW; ++mt)
+                            acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4(wbuf[kw][q][mt], j), f4(bc[r], j), acc[r][mt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // prefetch slice j: one activation fragment per slice, then (on the first channel group of a tap)
+                    // the weights of the next tap
+                    if (j < RW) bn[j] = *reinterpret_cast<const float4 *>(rptr[j] + off_n);
+                    if (j == 3) {
 #pragma unroll
-                for (int r = 0; r < RW; ++r)
+                        for (int r = 4; r < RW; ++r) bn[r] = *reinterpret_cast<const float4 *>(rptr[r] + off_n);
+                    }
+                    if (q == 0 && j >= 1) {
+                        // tap t+1 -> wbuf[(kw+1)%3]; Q*MTW loads spread over slices 1..3
+                        constexpr int NL = Q * MTW;
 #pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt)
-                        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4(w_cur[q][mt], j), f4(b_cur[r], j), acc[r][mt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                        for (int l = 0; l < NL; ++l)
+                            if (l % 3 == j - 1) {
+                                const int q2 = l / MTW, mt2 = l % MTW;
+                                wbuf[(kw + 1) % 3][q2][mt2] = wtap[((kw + 1) * Q + q2) * MT * 64 + mt2 * 64];
+                            }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (Q % 2 != 0) {
 #pragma unroll
-            for (int r = 0; r < RW; ++r) b_cur[r] = b_nxt[r];
+                    for (int r = 0; r < RW; ++r) bbuf[0][r] = bbuf[1][r];
+                }
+            }
         }
-#pragma unroll
-        for (int q = 0; q < Q; ++q)
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) w_cur[q][mt] = w_nxt[q][mt];
     }
 
     // ---- epilogue: D[i][j]: row i = 4*(lane>>4) + reg = output channel in the tile, col j = lane&15 = voxel.
@@ -355,9 +376,9 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
         const int half = it & 1, v = it >> 1;
         const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
         const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w)
-            c = *reinterpret_cast<const float4 *>(inb + (((int64_t)gd * h + gy) * w + gx) * 8 + half * 4);
+        const bool ok = gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        float4 c = *reinterpret_cast<const float4 *>(inb + (ok ? (((int64_t)gd * h + gy) * w + gx) * 8 + half * 4 : 0));
+        if (!ok) c = make_float4(0.f, 0.f, 0.f, 0.f);
         float *dst = lds + (half * 4) * PS + v;
         dst[0] = c.x;
         dst[PS] = c.y;
@@ -462,9 +483,9 @@ __global__ __launch_bounds__((LastCfg<C3, TD, TY, TX, FUSE>::NT)) void k_conv3d_
             const int c4 = it % C4, v = it / C4;
             const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
             const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-            c[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (it < Cfg::ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w)
-                c[i] = *reinterpret_cast<const float4 *>(ab + (((int64_t)gd * h + gy) * w + gx) * C3 + c4 * 4);
+            const bool ok = it < Cfg::ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            c[i] = *reinterpret_cast<const float4 *>(ab + (ok ? (((int64_t)gd * h + gy) * w + gx) * C3 + c4 * 4 : 0));
+            if (!ok) c[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < SITER; ++i) {
@@ -518,7 +539,7 @@ __global__ __launch_bounds__((LastCfg<C3, TD, TY, TX, FUSE>::NT)) void k_conv3d_
 size_t packed_mid_weight_floats(int c3)
 {
     if (c3 == 8) return 72 * 64;
-    return (size_t)27 * c3 * c3;
+    return (size_t)28 * c3 * c3;   // 27 taps + one all-zero tap (branch-free "next tap" prefetch in k_conv3d_mid16)
 }
 
 // w: [cout][cin][27] (Conv3D weight [Cout,Cin,3,3,3] flattened)

@@ -41,7 +41,7 @@ def main():
     for _ in range(5):
         pred = ops.disparity_stages(m._h, fl, fr, H, W)
     torch.cuda.synchronize()
-    _lib.check(lib.lws_profile_enable(m._h, 1))
+    _lib.check(lib.lws_profile_enable(m._h, -1))
     t0 = time.perf_counter()
     for _ in range(a.iters):
         pred = ops.disparity_stages(m._h, fl, fr, H, W)
