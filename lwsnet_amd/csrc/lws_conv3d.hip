@@ -346,7 +346,7 @@ struct Mid8Cfg {
 
 template <int TD, int TY>
 __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ in,      // [B,D,h,w,8]
-                                                     const float *__restrict__ wpk,     // [72][64] A fragments
+                                                     const float *__restrict__ wpk,     // [18][64][4] A fragments
                                                      const float *__restrict__ bn_s,    // next layer BN [8]
                                                      const float *__restrict__ bn_t,
                                                      float *__restrict__ out, int D, int h, int w,
@@ -367,9 +367,16 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
     const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * 8;
 
+    // 72 A fragments of this lane as 18 float4 ([step/4][lane][4]): 18 wide loads instead of 72 dword loads
     float wa[72];
 #pragma unroll
-    for (int s = 0; s < 72; ++s) wa[s] = wpk[s * 64 + lane];
+    for (int s4 = 0; s4 < 18; ++s4) {
+        const float4 v = reinterpret_cast<const float4 *>(wpk)[s4 * 64 + lane];
+        wa[4 * s4 + 0] = v.x;
+        wa[4 * s4 + 1] = v.y;
+        wa[4 * s4 + 2] = v.z;
+        wa[4 * s4 + 3] = v.w;
+    }
 
     // ---- stage: one item = half a voxel (4 channels, 16 B); scatter into 4 channel planes ----
     for (int it = tid; it < Cfg::NVOX * 2; it += 256) {
@@ -558,7 +565,7 @@ void pack_mid_weights(const float *w, int c3, float *out)
                             const int kw = t - xpar;
                             float v = 0.0f;
                             if (kw >= 0 && kw <= 2) v = w[(cout * 8 + cin) * 27 + (kd * 3 + kh) * 3 + kw];
-                            out[step * 64 + lane] = v;
+                            out[((step >> 2) * 64 + lane) * 4 + (step & 3)] = v;
                         }
                     }
         return;

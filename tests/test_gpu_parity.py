@@ -250,3 +250,34 @@ def test_forward_rejects_bad_sizes(dev, model):
         model(z, z)
     with pytest.raises(ValueError):
         model(np.zeros((1, 3, 64, 128), np.float32), np.zeros((1, 3, 64, 128), np.float32))   # W/8 < 24
+
+
+# ------------------------------------------------------------------ CLI (BASELINE config 1 plumbing)
+def test_inference_cli_writes_four_stage_maps(dev, hip_lib, tmp_path):
+    """`inference.py --left_img <dir>/left_test.png` contract (/root/reference/inference.py:65-70,113-122): the right
+    image is <dir>/right_test.png, inputs are cropped bottom-right to 368x1232, outputs are <dir>/1..4.png."""
+    from PIL import Image
+    from lwsnet_amd import checkpoint, imageio, inference
+    from lwsnet_amd.synth import make_pair
+    rng = np.random.default_rng(0)
+    H, W = 375, 1242                                   # KITTI size: exercises the crop rule
+    base = (rng.random((H, W, 3)) * 255).astype(np.uint8)
+    Image.fromarray(base).save(tmp_path / "left_test.png")
+    Image.fromarray(np.roll(base, -20, axis=1)).save(tmp_path / "right_test.png")
+    sd = make_state_dict(7)
+    checkpoint.save_pdparams(sd, tmp_path / "ckpt.pdparams")
+    written = inference.main(["--left_img", str(tmp_path / "left_test.png"), "--model", str(tmp_path / "ckpt.pdparams")])
+    assert [p.split("/")[-1] for p in written] == ["1.png", "2.png", "3.png", "4.png"]
+    for p in written:
+        im = np.asarray(Image.open(p))
+        assert im.shape == (368, 1232, 3) and im.dtype == np.uint8
+    # the maps are the model's own output on the cropped, normalised pair
+    from lwsnet_amd.models import LWSNet
+    m = LWSNet(default_args(), device=dev).set_state_dict(sd).eval()
+    l = imageio.to_input(imageio.crop_bottom_right(base))[None]
+    r = imageio.to_input(imageio.crop_bottom_right(np.roll(base, -20, axis=1)))[None]
+    pred = m(l, r)
+    want = imageio.disparity_to_color(pred[3][0, 0].cpu().numpy())
+    assert np.array_equal(np.asarray(Image.open(written[3])), want)
+    with pytest.raises(SystemExit):                    # inference.py:41-43: missing checkpoint
+        inference.main(["--left_img", str(tmp_path / "left_test.png"), "--model", str(tmp_path / "missing.pdparams")])
