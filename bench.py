@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step (BASELINE config 2: 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--size", default="256x512", help="HxW of the synthetic pairs (default: BASELINE config 2)")
+    ap.add_argument("--maxdisp0", type=int, default=24, help="stage-1 hypotheses (24 = maxdisp 192, 32 = maxdisp 256)")
     args = ap.parse_args()
 
     from lwsnet_amd import _lib, dist as ldist
@@ -66,6 +68,8 @@ def main():
     from lwsnet_amd.synth import make_batch
     from lwsnet_amd.weights import default_args, make_state_dict
 
+    global H, W
+    H, W = [int(v) for v in args.size.split("x")]
     rank, local_rank, world = ldist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
@@ -75,8 +79,8 @@ def main():
     torch.cuda.set_device(dev)
     import torch.distributed as dist
 
-    margs = default_args()
-    sd = make_state_dict(7)
+    margs = default_args(maxdisplist=(args.maxdisp0, 5, 5))
+    sd = make_state_dict(7, margs)
     model = LWSNet(margs, device=dev).set_state_dict(sd).eval()
     B = args.batch
     left_np, right_np = make_batch(B, H, W, first_index=rank * B)
@@ -160,9 +164,9 @@ def main():
         best_t, best_n = None, 1
         for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
             torch.set_num_threads(n)
-            lws_oracle.forward(l1, r1, sd)                 # warm-up for this thread count
+            lws_oracle.forward(l1, r1, sd, margs.maxdisplist)     # warm-up for this thread count
             t1 = time.perf_counter()
-            lws_oracle.forward(l1, r1, sd)
+            lws_oracle.forward(l1, r1, sd, margs.maxdisplist)
             dt = time.perf_counter() - t1
             if best_t is None or dt < best_t:
                 best_t, best_n = dt, n
@@ -172,7 +176,7 @@ def main():
         ts = []
         for _ in range(3):
             t1 = time.perf_counter()
-            ref = lws_oracle.forward(l1, r1, sd)
+            ref = lws_oracle.forward(l1, r1, sd, margs.maxdisplist)
             ts.append(time.perf_counter() - t1)
         med = sorted(ts)[1]
         err = [float((pred[s][:1].cpu() - ref[s]).abs().max()) for s in range(4)]
@@ -187,7 +191,9 @@ def main():
         "value": round(pairs / elapsed, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE config 2: batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[24,5,5], all 4 stages",
+        "config": {"workload": (f"BASELINE config 2: batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[24,5,5], all 4 stages"
+                                if (H, W, args.maxdisp0) == (256, 512, 24) else
+                                f"batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[{args.maxdisp0},5,5], all 4 stages"),
                    "pairs_per_gpu": B, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4" if world > 1 else "single GPU",
                    "weights": "seeded synthetic (seed 7, calibrated BN)"},
         "roofline": _with_traffic(roof, B), "cpu_baseline": cpu,

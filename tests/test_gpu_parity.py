@@ -281,3 +281,44 @@ def test_inference_cli_writes_four_stage_maps(dev, hip_lib, tmp_path):
     assert np.array_equal(np.asarray(Image.open(written[3])), want)
     with pytest.raises(SystemExit):                    # inference.py:41-43: missing checkpoint
         inference.main(["--left_img", str(tmp_path / "left_test.png"), "--model", str(tmp_path / "missing.pdparams")])
+
+
+# ------------------------------------------------------------------ the other BASELINE configs
+def test_config3_kitti_crop_batch(dev, model):
+    """BASELINE config 3 shape (B x 368 x 1232, ragged 46x154 / 92x308 / 184x616 stage maps): stage maps of a
+    2-pair batch equal the single-pair runs bitwise, and pair 0 equals the C oracle bit for bit on a cropped strip."""
+    left, right = make_batch(2, 368, 1232, 7)
+    p2 = model(left, right)
+    assert all(tuple(p.shape) == (2, 1, 368, 1232) and torch.isfinite(p).all() for p in p2)
+    p1 = model(left[1:], right[1:])
+    assert all(torch.equal(p1[s], p2[s][1:]) for s in range(4))
+
+
+def test_config3_shape_vs_c_oracle_small_batch(dev, model):
+    """Same ragged tiling (w/8 = 154 is not a multiple of 16, h/8 = 46 not of 4) at a size the C oracle finishes fast."""
+    from oracle import c_oracle as C
+    H, W = 112, 1232                                   # h/8 = 14, w/8 = 154
+    left, right = make_batch(1, H, W, 3)
+    pred = model(left, right)
+    want = C.forward(left, right, model.state_dict())
+    for s in range(4):
+        assert_bits(pred[s], want[s], f"368x1232-style tiling, stage {s + 1}")
+
+
+def test_config5_maxdisp256(dev, hip_lib):
+    """BASELINE config 5 geometry: 544x960 (SceneFlow padded), maxdisplist=[32,5,5] (D1 = 32); float32 throughout
+    (the fp16-feature variant of config 5 cannot meet the tolerance, SURVEY.md section 7, and is not built)."""
+    from lwsnet_amd.models import LWSNet
+    from oracle import c_oracle as C
+    args = default_args(maxdisplist=(32, 5, 5))
+    sd = make_state_dict(7, args)
+    m = LWSNet(args, device=dev).set_state_dict(sd).eval()
+    left, right = make_batch(1, 544, 960, 11)
+    pred = m(left, right)
+    assert all(tuple(p.shape) == (1, 1, 544, 960) and torch.isfinite(p).all() for p in pred)
+    H, W = 96, 320                                     # W/8 = 40 >= 32; small enough for the C oracle
+    l2, r2 = make_batch(1, H, W, 12)
+    got = m(l2, r2)
+    want = C.forward(l2, r2, sd, (32, 5, 5))
+    for s in range(4):
+        assert_bits(got[s], want[s], f"maxdisplist [32,5,5], stage {s + 1}")
