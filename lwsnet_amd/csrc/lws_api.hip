@@ -343,7 +343,7 @@ static void build_net2d(const lws_ctx *h, std::vector<float> &slab, Net2dOffsets
         fold_bn(h, "refinement2.0.0", s, t);
         o.r2f_s = sb.put(s);
         o.r2f_t = sb.put(t);
-        std::vector<float> wp(9 * 4 * 2 * 64 * 4);
+        std::vector<float> wp(10 * 4 * 2 * 64 * 4, 0.0f);   // 9 taps + one all-zero tap (prefetch without bounds check)
         pack_conv2d_mfma(h->host.at("refinement2.0.2.weight").data(), 64, 9, wp.data());   // [32][64][3][3]
         o.r2f_w = sb.put(wp);
     }
@@ -385,8 +385,11 @@ static void bind_net2d(lws_ctx *h, const Net2dOffsets &o)
 }
 
 // feature_extraction.forward (submodules.py:176-188) on N images; first layer may read two separate inputs
+// If tail != nullptr the layers after the 1/8 map (conv5, conv6, classif1 -> f4, f2) run on that stream: stage 1
+// needs only f8, so they overlap with it; ev[0] = f8 done (recorded on st), ev[1] = f4 done, ev[2] = f2 done (on tail).
 static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, int nA, int nB, int H, int W,
-                              const WsLayout &L, float *f8, float *f4, float *f2, hipStream_t st)
+                              const WsLayout &L, float *f8, float *f4, float *f2, hipStream_t st,
+                              hipStream_t tail = nullptr, hipEvent_t *ev = nullptr)
 {
     const Net2d &n = h->net2d;
     const int N = nA + nB, H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
@@ -409,10 +412,17 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
     LWS_FE(launch_conv2d_nchw(n.fe[5], c1, nullptr, pre, N, H4, W4, st));                                   // conv2 -> pre
     LWS_FE(launch_conv2d_nchw(n.fe[6], pre, nullptr, c3, N, H4, W4, st));                                   // conv3 (1/8)
     LWS_FE(launch_conv2d_nchw(n.fe[7], c3, nullptr, f8, N, H8, W8, st));                                    // conv4 -> f8
+    if (tail != nullptr) {
+        LWS_HIP(hipEventRecord(ev[0], st));
+        LWS_HIP(hipStreamWaitEvent(tail, ev[0], 0));
+        st = tail;
+    }
     LWS_FE(launch_conv2d_nchw(n.fe[8], f8, pre, f4, N, H8, W8, st));                                        // relu(conv5 + pre) (:103)
+    if (tail != nullptr) LWS_HIP(hipEventRecord(ev[1], tail));
     LWS_FE(launch_conv2d_nchw(n.fe[9], f4, o2, o3, N, H4, W4, st));                                         // conv6 + output (:106,:182)
     LWS_FE(launch_conv2d_nchw(n.fe[10], o3, nullptr, cls, N, H2, W2, st));                                  // classif1.0
     LWS_FE(launch_conv2d_nchw(n.fe[11], cls, nullptr, f2, N, H2, W2, st));                                  // classif1.2 -> f2
+    if (tail != nullptr) LWS_HIP(hipEventRecord(ev[2], tail));
 #undef LWS_FE
     return LWS_OK;
 }
@@ -461,7 +471,7 @@ static int refine_rest(lws_ctx *h, const float *pred3, int B, int H, int W, cons
 #undef LWS_RF
 
 static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *const featsR[3], int B, int H, int W,
-                       float *const pred_out[3], const WsLayout &L, hipStream_t st);
+                       float *const pred_out[3], const WsLayout &L, hipStream_t st, hipEvent_t *feat_ready = nullptr);
 
 }  // namespace lws
 
@@ -469,8 +479,9 @@ using namespace lws;
 
 namespace lws {
 
+// feat_ready (optional): events after which the stage-2 / stage-3 feature maps are complete (feat_ready[1], [2])
 static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *const featsR[3], int B, int H, int W,
-                       float *const pred_out[3], const WsLayout &L, hipStream_t st)
+                       float *const pred_out[3], const WsLayout &L, hipStream_t st, hipEvent_t *feat_ready)
 {
     int rc;
     float *act_a = h->ws + L.act_a, *act_b = h->ws + L.act_b, *raw = h->ws + L.cost_raw, *cost = h->ws + L.cost_out,
@@ -479,6 +490,7 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
     for (int s = 0; s < 3; ++s) {
         int D, hh, ww;
         stage_dims(h, s, H, W, D, hh, ww);
+        if (s > 0 && feat_ready != nullptr) LWS_HIP(hipStreamWaitEvent(st, feat_ready[s], 0));
         if (s == 0) {
             ProfScope p(h, LWS_KC_VOLUME_SHIFT, st);
             rc = launch_volume_l1_shift(featsL[0], featsR[0], raw, B, feat_c[0], hh, ww, D, st);            // :131
@@ -593,6 +605,7 @@ int lws_destroy(lws_handle h)
         (void)hipStreamDestroy(h->side);
         (void)hipEventDestroy(h->ev_fork);
         (void)hipEventDestroy(h->ev_join);
+        for (int i = 0; i < 3; ++i) (void)hipEventDestroy(h->ev_feat[i]);
     }
     if (h->params) (void)hipFree(h->params);
     if (h->ws) (void)hipFree(h->ws);
@@ -825,6 +838,7 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
         LWS_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         LWS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         LWS_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) LWS_HIP(hipEventCreateWithFlags(&h->ev_feat[i], hipEventDisableTiming));
     }
     LWS_HIP(hipEventRecord(h->ev_fork, st));
     LWS_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -832,13 +846,13 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     if (rc) return rc;
     LWS_HIP(hipEventRecord(h->ev_join, h->side));
     float *f8 = h->ws + L.fe_f8, *f4 = h->ws + L.fe_f4, *f2 = h->ws + L.fe_f2;
-    rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st);            // models.py:110-111
+    rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st, h->side, h->ev_feat);   // models.py:110-111
     if (rc) return rc;
     const size_t n8 = (size_t)B * 16 * (H / 8) * (W / 8), n4 = (size_t)B * 16 * (H / 4) * (W / 4),
                  n2 = (size_t)B * 8 * (H / 2) * (W / 2);
     const float *fl[3] = {f8, f4, f2};
     const float *fr[3] = {f8 + n8, f4 + n4, f2 + n2};
-    rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st);                              // :115-156
+    rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st, h->ev_feat);                  // :115-156
     if (rc) return rc;
     LWS_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     return refine_rest(h, pred_out[2], B, H, W, L, pred_out[3], st);                    // :159-162

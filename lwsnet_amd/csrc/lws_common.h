@@ -106,6 +106,7 @@ struct lws_ctx {
     // side stream for the branch of the forward that depends on the left image only
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_feat[3] = {nullptr, nullptr, nullptr};   // f8 / f4 / f2 complete
 };
 
 namespace lws {

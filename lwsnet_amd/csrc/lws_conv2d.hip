@@ -50,15 +50,24 @@ __global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ i
     const int rx0 = TRANSPOSED ? ((ox0 - 1) >> 1) : ox0 * stride - pad;
     const int plane = H * W, oplane = Ho * Wo;
     const float *inb = in + (int64_t)b * CIN * plane;
-    const int rsz = RH * RW, total = CIN * rsz;
-#pragma unroll 8
-    for (int i = tid; i < total; i += 256) {
-        const int ci = i / rsz, r = i - ci * rsz;
-        const int ry = r / RW, rx = r - ry * RW;
-        const int gy = ry0 + ry, gx = rx0 + rx;
-        const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const float v = inb[ok ? ci * plane + gy * W + gx : 0];   // unconditional load, masked after
-        sIn[(ci * RH + ry) * RWp + rx] = ok ? v : 0.0f;
+    // region positions are decoded once per thread (<= 2 positions: RH*RW <= 19*19), then all CIN planes of a
+    // position are loaded back to back (unconditional clamped loads, masked afterwards)
+    const int rsz = RH * RW;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = tid + 256 * k;
+        if (r < rsz) {
+            const int ry = r / RW, rx = r - ry * RW;
+            const int gy = ry0 + ry, gx = rx0 + rx;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float *src = inb + (ok ? gy * W + gx : 0);
+            float v[CIN];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) v[ci] = src[ci * plane];
+            float *dst = sIn + ry * RWp + rx;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) dst[ci * RH * RWp] = ok ? v[ci] : 0.0f;
+        }
     }
     __syncthreads();
     const int ox = ox0 + tx, oy = oy0 + ty;
@@ -406,12 +415,13 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
             }
         }
     }
+    // weights [tap][qq][mt][lane] (+ one all-zero tap so the next-tap prefetch needs no bounds check)
     const float4 *wp = wpk + lane;
-    float4 w_cur[4][2], w_nxt[4][2];
+    float4 wbuf[2][4][2];                           // ping-pong over taps (copied once per tap: 8 v_mov per 32 MFMAs)
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) w_cur[qq][mt] = wp[(qq * 2 + mt) * 64];
+        for (int mt = 0; mt < 2; ++mt) wbuf[0][qq][mt] = wp[(qq * 2 + mt) * 64];
     __syncthreads();
 
     floatx4 acc[RW][2];
@@ -424,36 +434,37 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
         const int hp = (RW * wave + r + tap / 3) * RH_X + n + tap % 3;
         return *reinterpret_cast<const float4 *>(&sA[(qq >> 1) * NPX * RVS + swz(hp, 4 * (qq & 1) + g)]);
     };
-    float4 b_cur[RW], b_nxt[RW];
+    // 4 steps per tap (even): activation fragments ping-pong by step parity; prefetches are issued in fenced slices
+    // between the MFMA groups of the current step (see k_conv3d_mid16)
+    float4 bbuf[2][RW];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) b_cur[r] = frag(r, 0, 0);
+    for (int r = 0; r < RW; ++r) bbuf[0][r] = frag(r, 0, 0);
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
         const int tn = tap < 8 ? tap + 1 : 8;
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) w_nxt[qq][mt] = wp[((tn * 4 + qq) * 2 + mt) * 64];
-#pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
+            float4 *bc = bbuf[qq & 1], *bn = bbuf[(qq & 1) ^ 1];
 #pragma unroll
-            for (int r = 0; r < RW; ++r) b_nxt[r] = qq < 3 ? frag(r, tap, qq + 1) : frag(r, tn, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int r = 0; r < RW; ++r)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(w_cur[qq][mt], j), f4c(b_cur[r], j), acc[r][mt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < RW; ++r) b_cur[r] = b_nxt[r];
+                        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(wbuf[0][qq][mt], j), f4c(bc[r], j), acc[r][mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j < RW) bn[j] = qq < 3 ? frag(j, tap, qq + 1) : frag(j, tn, 0);
+                if (j >= 2) {      // next tap's 8 weight fragments: one per (qq, j in {2,3})
+                    const int l = qq * 2 + (j - 2);
+                    wbuf[1][l >> 1][l & 1] = wp[(((tap + 1) * 4 + (l >> 1)) * 2 + (l & 1)) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) w_cur[qq][mt] = w_nxt[qq][mt];
+            for (int mt = 0; mt < 2; ++mt) wbuf[0][qq][mt] = wbuf[1][qq][mt];
     }
     float *outb = out + (int64_t)t.b * H * W * 32;
     const int gx = t.X0 + n * dil;
@@ -472,37 +483,59 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
 
 // =============================================================================================
 // refinement2[5] + skip (submodules.py:318-325, models.py:161-162): Conv 3x3 pad 1, 32 -> 1, plus pred3.
-// One thread = one pixel; 9 taps x 32 channels from the channels-last map (8 float4 per tap).
 // =============================================================================================
+constexpr int LAST_TY = 8, LAST_TX = 32, LAST_HY = LAST_TY + 2, LAST_HX = LAST_TX + 2, LAST_NPX = LAST_HY * LAST_HX;
+constexpr int LAST_PS = 346;     // plane stride in float4 (>= 340)
+
 __global__ __launch_bounds__(256) void k_ref_last(const float *__restrict__ in, const float *__restrict__ wgt,   // [tap][32]
                                                   const float *__restrict__ pred3, float *__restrict__ out, int H, int W)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
-    if (x >= W || y >= H) return;
+    // Workgroup = 8 x 32 output pixels, one per thread; the 10 x 34 halo tile is staged in LDS planar by 4-channel
+    // group (a wave's ds_read_b128 of 64 neighbouring pixels in one plane is 1 KiB contiguous: conflict-free).
+    __shared__ float4 sA[8 * LAST_PS];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int x0 = blockIdx.x * LAST_TX, y0 = blockIdx.y * LAST_TY;
     const float *inb = in + (int64_t)b * H * W * 32;
+    constexpr int ITEMS = LAST_NPX * 8, SITER = (ITEMS + 255) / 256;
+    const int c4 = tid & 7;
+    float4 c[SITER];
+    bool okv[SITER];
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int hp = (tid >> 3) + 32 * i;
+        const int hy = hp / LAST_HX, hx = hp - hy * LAST_HX;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        okv[i] = hp < LAST_NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        c[i] = *reinterpret_cast<const float4 *>(inb + (okv[i] ? (gy * W + gx) * 32 + c4 * 4 : 0));
+    }
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int hp = (tid >> 3) + 32 * i;
+        if (hp < LAST_NPX) sA[c4 * LAST_PS + hp] = okv[i] ? c[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const int tx = tid & 31, ty = tid >> 5;
+    const int x = x0 + tx, y = y0 + ty;
     float acc = 0.0f;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int iy = y + kh - 1;
-        if (iy < 0 || iy >= H) continue;
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-            const int ix = x + kw - 1;
-            if (ix < 0 || ix >= W) continue;
-            const float4 *p = reinterpret_cast<const float4 *>(inb + ((int64_t)iy * W + ix) * 32);
+            const float4 *p = sA + (ty + kh) * LAST_HX + tx + kw;
             const float *w = wgt + (kh * 3 + kw) * 32;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float4 a = p[c];
-                acc = fmaf(a.x, w[c * 4 + 0], acc);
-                acc = fmaf(a.y, w[c * 4 + 1], acc);
-                acc = fmaf(a.z, w[c * 4 + 2], acc);
-                acc = fmaf(a.w, w[c * 4 + 3], acc);
+            for (int g8 = 0; g8 < 8; ++g8) {
+                const float4 a = p[g8 * LAST_PS];
+                acc = fmaf(a.x, w[g8 * 4 + 0], acc);
+                acc = fmaf(a.y, w[g8 * 4 + 1], acc);
+                acc = fmaf(a.z, w[g8 * 4 + 2], acc);
+                acc = fmaf(a.w, w[g8 * 4 + 3], acc);
             }
         }
+    if (x < W && y < H) {
+        const int64_t o = ((int64_t)b * H + y) * W + x;
+        out[o] = acc + pred3[o];
     }
-    const int64_t o = ((int64_t)b * H + y) * W + x;
-    out[o] = acc + pred3[o];
 }
 
 // =============================================================================================
@@ -534,20 +567,34 @@ int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, i
 int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, float *out, int B, int H, int W,
                       hipStream_t st)
 {
-    // 4-row tiles: 27 KB of LDS per workgroup -> 5 workgroups (5 waves per SIMD) share each CU's MFMA pipes
-    constexpr int TY = 4;
+    static const int variant = [] {
+        const char *e = getenv("LWS_CONV64_VARIANT");
+        return e ? atoi(e) : 1;
+    }();
     const int dil = 8;
-    const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, TY * dil);
-    dim3 grid(nbx * nby * dil * dil * B), block(256);
-    hipLaunchKernelGGL(k_ref_conv64<TY>, grid, block, 0, st, inL, inD, l.bn_s, l.bn_t,
-                       reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby);
+    // variant 1 (default): 8-row tiles, 2 rows per wave -- each streamed weight fragment feeds 8 MFMAs instead of 4
+    // (measured r01: 52 / 345 us at B = 1 / 8 vs 56 / 387 us for the 4-row tile, which fits 5 workgroups per CU)
+    if (variant == 1) {
+        constexpr int TY = 8;
+        const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, TY * dil);
+        dim3 grid(nbx * nby * dil * dil * B), block(256);
+        hipLaunchKernelGGL(k_ref_conv64<TY>, grid, block, 0, st, inL, inD, l.bn_s, l.bn_t,
+                           reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby);
+    } else {
+        // 4-row tiles: 27 KB of LDS per workgroup -> 5 workgroups (5 waves per SIMD) share each CU's MFMA pipes
+        constexpr int TY = 4;
+        const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, TY * dil);
+        dim3 grid(nbx * nby * dil * dil * B), block(256);
+        hipLaunchKernelGGL(k_ref_conv64<TY>, grid, block, 0, st, inL, inD, l.bn_s, l.bn_t,
+                           reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby);
+    }
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
 
 int launch_ref_last(const float *in, const float *w, const float *pred3, float *out, int B, int H, int W, hipStream_t st)
 {
-    dim3 grid(cdiv(W, 64), cdiv(H, 4), B), block(64, 4);
+    dim3 grid(cdiv(W, LAST_TX), cdiv(H, LAST_TY), B), block(256);
     hipLaunchKernelGGL(k_ref_last, grid, block, 0, st, in, w, pred3, out, H, W);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
