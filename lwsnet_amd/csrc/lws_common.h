@@ -107,6 +107,8 @@ struct lws_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_feat[3] = {nullptr, nullptr, nullptr};   // f8 / f4 / f2 complete
+    hipStream_t side2 = nullptr;                            // right-image feature layers
+    hipEvent_t ev_right = nullptr;
 };
 
 namespace lws {
