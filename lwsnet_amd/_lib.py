@@ -55,6 +55,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP/HSA runtime (torch/lib/libamdhip64.so).  It must be the first HIP runtime in
+    # the process: loading this library first pulls /opt/rocm's copy in, and the second runtime then reports "no
+    # ROCm-capable device".  With torch imported first, the SONAME libamdhip64.so.7 resolves to torch's copy and both
+    # share one runtime (device pointers and streams interoperate).
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <functional>
+
 #include "lws_common.h"
 
 namespace lws {
@@ -385,8 +387,11 @@ static void bind_net2d(lws_ctx *h, const Net2dOffsets &o)
 }
 
 // feature_extraction.forward (submodules.py:176-188) on N images; first layer may read two separate inputs
-// If tail != nullptr the layers after the 1/8 map (conv5, conv6, classif1 -> f4, f2) run on that stream: stage 1
-// needs only f8, so they overlap with it; ev[0] = f8 done (recorded on st), ev[1] = f4 done, ev[2] = f2 done (on tail).
+static int feature_tail(lws_ctx *h, int N, int H, int W, const WsLayout &L, float *f8, float *f4, float *f2,
+                        hipStream_t st, hipEvent_t *ev);
+
+// If tail != nullptr only the layers up to the 1/8 map run here (stage 1 needs nothing else); the caller runs
+// feature_tail (conv5, conv6, classif1 -> f4, f2) on the `tail` stream later, overlapped with the volume stages.
 static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, int nA, int nB, int H, int W,
                               const WsLayout &L, float *f8, float *f4, float *f2, hipStream_t st,
                               hipStream_t tail = nullptr, hipEvent_t *ev = nullptr)
@@ -395,7 +400,7 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
     const int N = nA + nB, H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
     float *ws = h->ws;
     float *a0 = ws + L.fe_a0, *o = ws + L.fe_o, *a2 = ws + L.fe_a2, *o2 = ws + L.fe_o2, *c1 = ws + L.fe_c1,
-          *pre = ws + L.fe_pre, *c3 = ws + L.fe_c3, *o3 = ws + L.fe_o3, *cls = ws + L.fe_cls;
+          *pre = ws + L.fe_pre, *c3 = ws + L.fe_c3;
     int rc;
 #define LWS_FE(call)                                   \
     {                                                  \
@@ -447,17 +452,34 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
             (void)s0;
         }
     }
-    if (tail != nullptr) {
-        LWS_HIP(hipEventRecord(ev[0], st));
-        LWS_HIP(hipStreamWaitEvent(tail, ev[0], 0));
-        st = tail;
-    }
+#undef LWS_FE
+    if (tail != nullptr) return LWS_OK;
+    (void)ev;
+    return feature_tail(h, N, H, W, L, f8, f4, f2, st, nullptr);
+}
+
+// conv5 (-> f4), conv6, classif1 (-> f2), submodules.py:103-107,182-186.  ev (optional): ev[1] recorded after f4,
+// ev[2] after f2, on st.
+static int feature_tail(lws_ctx *h, int N, int H, int W, const WsLayout &L, float *f8, float *f4, float *f2,
+                        hipStream_t st, hipEvent_t *ev)
+{
+    const Net2d &n = h->net2d;
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+    float *ws = h->ws;
+    float *o2 = ws + L.fe_o2, *pre = ws + L.fe_pre, *o3 = ws + L.fe_o3, *cls = ws + L.fe_cls;
+    int rc;
+#define LWS_FE(call)                                   \
+    {                                                  \
+        ProfScope p_(h, LWS_KC_FEATURE2D, st);         \
+        rc = (call);                                   \
+    }                                                  \
+    if (rc) return rc;
     LWS_FE(launch_conv2d_nchw(n.fe[8], f8, pre, f4, N, H8, W8, st));                                        // relu(conv5 + pre) (:103)
-    if (tail != nullptr) LWS_HIP(hipEventRecord(ev[1], tail));
+    if (ev != nullptr) LWS_HIP(hipEventRecord(ev[1], st));
     LWS_FE(launch_conv2d_nchw(n.fe[9], f4, o2, o3, N, H4, W4, st));                                         // conv6 + output (:106,:182)
     LWS_FE(launch_conv2d_nchw(n.fe[10], o3, nullptr, cls, N, H2, W2, st));                                  // classif1.0
     LWS_FE(launch_conv2d_nchw(n.fe[11], cls, nullptr, f2, N, H2, W2, st));                                  // classif1.2 -> f2
-    if (tail != nullptr) LWS_HIP(hipEventRecord(ev[2], tail));
+    if (ev != nullptr) LWS_HIP(hipEventRecord(ev[2], st));
 #undef LWS_FE
     return LWS_OK;
 }
@@ -506,7 +528,8 @@ static int refine_rest(lws_ctx *h, const float *pred3, int B, int H, int W, cons
 #undef LWS_RF
 
 static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *const featsR[3], int B, int H, int W,
-                       float *const pred_out[3], const WsLayout &L, hipStream_t st, hipEvent_t *feat_ready = nullptr);
+                       float *const pred_out[3], const WsLayout &L, hipStream_t st, hipEvent_t *feat_ready = nullptr,
+                       const std::function<int()> &after_stage1_stack = nullptr);
 
 }  // namespace lws
 
@@ -516,7 +539,8 @@ namespace lws {
 
 // feat_ready (optional): events after which the stage-2 / stage-3 feature maps are complete (feat_ready[1], [2])
 static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *const featsR[3], int B, int H, int W,
-                       float *const pred_out[3], const WsLayout &L, hipStream_t st, hipEvent_t *feat_ready)
+                       float *const pred_out[3], const WsLayout &L, hipStream_t st, hipEvent_t *feat_ready,
+                       const std::function<int()> &after_stage1_stack)
 {
     int rc;
     float *act_a = h->ws + L.act_a, *act_b = h->ws + L.act_b, *raw = h->ws + L.cost_raw, *cost = h->ws + L.cost_out,
@@ -539,6 +563,10 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         bool fused = false;
         rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st, low, start, &fused);              // :136-138
         if (rc) return rc;
+        if (s == 0 && after_stage1_stack) {
+            rc = after_stage1_stack();
+            if (rc) return rc;
+        }
         if (!fused) {
             ProfScope p(h, LWS_KC_SOFTARGMIN, st);
             rc = launch_softargmin(cost, low, B, D, hh, ww, start, st);                                      // :142,151
@@ -892,7 +920,15 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
                  n2 = (size_t)B * 8 * (H / 2) * (W / 2);
     const float *fl[3] = {f8, f4, f2};
     const float *fr[3] = {f8 + n8, f4 + n4, f2 + n2};
-    rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st, h->ev_feat);                  // :115-156
+    // The rest of the feature extractor (f4 for stage 2, f2 for stage 3) is launched on the side stream right after
+    // stage 1's Conv3D stack: it overlaps with stage 1's regression and with stage 2 instead of competing with the
+    // MFMA-bound stage-1 kernels for the CUs.
+    auto launch_tail = [&]() -> int {
+        LWS_HIP(hipEventRecord(h->ev_feat[0], st));
+        LWS_HIP(hipStreamWaitEvent(h->side, h->ev_feat[0], 0));
+        return feature_tail(h, 2 * B, H, W, L, f8, f4, f2, h->side, h->ev_feat);
+    };
+    rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st, h->ev_feat, launch_tail);     // :115-156
     if (rc) return rc;
     LWS_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     return refine_rest(h, pred_out[2], B, H, W, L, pred_out[3], st);                    // :159-162
