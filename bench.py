@@ -59,6 +59,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step (BASELINE config 2: 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent handles/HIP streams the steps rotate over (1 = every step on one stream; >1 "
+                         "overlaps consecutive steps: higher pairs/s, but kernels then share CUs and their in-situ "
+                         "durations -- hence roofline.frac -- grow)")
     ap.add_argument("--size", default="256x512", help="HxW of the synthetic pairs (default: BASELINE config 2)")
     ap.add_argument("--maxdisp0", type=int, default=24, help="stage-1 hypotheses (24 = maxdisp 192, 32 = maxdisp 256)")
     args = ap.parse_args()
@@ -81,19 +85,33 @@ def main():
 
     margs = default_args(maxdisplist=(args.maxdisp0, 5, 5))
     sd = make_state_dict(7, margs)
-    model = LWSNet(margs, device=dev).set_state_dict(sd).eval()
+    S = max(1, args.streams)
+    models = [LWSNet(margs, device=dev).set_state_dict(sd).eval() for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
+    model = models[0]
     B = args.batch
     left_np, right_np = make_batch(B, H, W, first_index=rank * B)
     left, right = torch.from_numpy(left_np).to(dev), torch.from_numpy(right_np).to(dev)
     lib = _lib.load()
-    _lib.check(lib.lws_reserve(model._h, B, H, W), "lws_reserve")
+    for m in models:
+        _lib.check(lib.lws_reserve(m._h, B, H, W), "lws_reserve")
 
     gathered = [torch.empty((B, 1, H, W), device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
 
+    counter = [0]
+
     def step():
-        pred = model(left, right)
-        if world > 1:
-            dist.gather(pred[3], gathered, dst=0)
+        i = counter[0] % S
+        counter[0] += 1
+        if S == 1:
+            pred = models[0](left, right)
+            if world > 1:
+                dist.gather(pred[3], gathered, dst=0)
+            return pred
+        with torch.cuda.stream(streams[i]):
+            pred = models[i](left, right)
+            if world > 1:
+                dist.gather(pred[3], gathered, dst=0)
         return pred
 
     for _ in range(args.warmup):
@@ -101,7 +119,8 @@ def main():
     # inside the timed region only the dominant kernel class is bracketed by hipEvents (8 events per step);
     # the per-class breakdown comes from a separate, untimed pass below
     KC_MID16 = 3
-    _lib.check(lib.lws_profile_enable(model._h, 1 << KC_MID16), "lws_profile_enable")
+    for m in models:
+        _lib.check(lib.lws_profile_enable(m._h, 1 << KC_MID16), "lws_profile_enable")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -114,13 +133,18 @@ def main():
     elapsed = time.perf_counter() - t0
     tot = (ctypes.c_double * _lib.LWS_KC_COUNT)()
     cnt = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
-    _lib.check(lib.lws_profile_read(model._h, tot, cnt), "lws_profile_read")
-    mid_avg_us = 1e3 * tot[KC_MID16] / max(cnt[KC_MID16], 1)
+    mid_ms, mid_n = 0.0, 0
+    for m in models:
+        _lib.check(lib.lws_profile_read(m._h, tot, cnt), "lws_profile_read")
+        _lib.check(lib.lws_profile_enable(m._h, 0), "lws_profile_enable")
+        mid_ms += tot[KC_MID16]
+        mid_n += cnt[KC_MID16]
+    mid_avg_us = 1e3 * mid_ms / max(mid_n, 1)
     # untimed breakdown pass: every kernel class, 10 steps
     nb = 10
     _lib.check(lib.lws_profile_enable(model._h, -1), "lws_profile_enable")
     for _ in range(nb):
-        step()
+        models[0](left, right)
     torch.cuda.synchronize()
     _lib.check(lib.lws_profile_read(model._h, tot, cnt), "lws_profile_read")
     _lib.check(lib.lws_profile_enable(model._h, 0), "lws_profile_enable")
@@ -194,7 +218,7 @@ def main():
         "config": {"workload": (f"BASELINE config 2: batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[24,5,5], all 4 stages"
                                 if (H, W, args.maxdisp0) == (256, 512, 24) else
                                 f"batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[{args.maxdisp0},5,5], all 4 stages"),
-                   "pairs_per_gpu": B, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4" if world > 1 else "single GPU",
+                   "pairs_per_gpu": B, "streams": S, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4" if world > 1 else "single GPU",
                    "weights": "seeded synthetic (seed 7, calibrated BN)"},
         "roofline": _with_traffic(roof, B), "cpu_baseline": cpu,
         "hot_path_kernel_ms_per_step": round(hot_ms, 4), "all_kernel_ms_per_step": round(all_ms, 4), "kernels": {k: {a: round(b, 2) for a, b in v.items()} for k, v in kernels.items()},
