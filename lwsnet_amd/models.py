@@ -38,7 +38,8 @@ class LWSNet:
         cfg = _lib.LwsConfig((ctypes.c_int32 * 3)(*self.maxdisplist), self.layers_3d, self.channels_3d,
                              (ctypes.c_int32 * 3)(*self.growth_rate))
         self._h = ctypes.c_void_p()
-        _lib.check(lib.lws_create(ctypes.byref(cfg), ctypes.byref(self._h)), "lws_create")
+        with self._device_ctx():
+            _lib.check(lib.lws_create(ctypes.byref(cfg), ctypes.byref(self._h)), "lws_create")
 
     def __del__(self):
         h = getattr(self, "_h", None)
