@@ -142,20 +142,36 @@ __global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict_
 
     const float *Lp = L + (int64_t)b * C * plane + pix;
     const float *Rp = R + (int64_t)b * C * plane;
-    const int64_t o_nw = (int64_t)y0 * w + x0, o_ne = o_nw + 1, o_sw = o_nw + w, o_se = o_sw + 1;
+    // Taps are loaded UNCONDITIONALLY from clamped addresses (an invalid tap reads element 0 and is masked below), so
+    // that all 2-4 gathers and the L load of every channel are in flight together instead of one branch per tap.
+    const bool b_nw = vy0 && vx0, b_ne = vy0 && vx1, b_sw = south && vy1 && vx0, b_se = south && vy1 && vx1;
+    const int o_nw = b_nw ? y0 * w + x0 : 0, o_ne = b_ne ? y0 * w + x1 : 0;
+    const int o_sw = b_sw ? y1 * w + x0 : 0, o_se = b_se ? y1 * w + x1 : 0;
     float acc = 0.0f;
-#pragma unroll 4
-    for (int c = 0; c < C; ++c) {
-        const float *rp = Rp + (int64_t)c * plane;
-        float s = 0.0f;
-        if (vy0 && vx0) s = s + rp[o_nw] * w_nw;
-        if (vy0 && vx1) s = s + rp[o_ne] * w_ne;
-        if (south) {
-            if (vy1 && vx0) s = s + rp[o_sw] * w_sw;
-            if (vy1 && vx1) s = s + rp[o_se] * w_se;
+    if (!south) {                                   // wave-uniform in practice (iy depends on the row only)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float *rp = Rp + (int64_t)c * plane;
+            const float r_nw = rp[o_nw], r_ne = rp[o_ne];
+            const float l = Lp[(int64_t)c * plane];
+            float s = 0.0f;
+            if (b_nw) s = s + r_nw * w_nw;
+            if (b_ne) s = s + r_ne * w_ne;
+            acc = acc + fabsf(l - s);                    // :101
         }
-        float l = Lp[(int64_t)c * plane];
-        acc = acc + fabsf(l - s);                        // :101
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float *rp = Rp + (int64_t)c * plane;
+            const float r_nw = rp[o_nw], r_ne = rp[o_ne], r_sw = rp[o_sw], r_se = rp[o_se];
+            const float l = Lp[(int64_t)c * plane];
+            float s = 0.0f;
+            if (b_nw) s = s + r_nw * w_nw;
+            if (b_ne) s = s + r_ne * w_ne;
+            if (b_sw) s = s + r_sw * w_sw;
+            if (b_se) s = s + r_se * w_se;
+            acc = acc + fabsf(l - s);                    // :101
+        }
     }
     cost[((int64_t)b * (2 * m - 1) + k) * plane + pix] = acc;
 }
