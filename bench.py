@@ -204,10 +204,12 @@ def main():
             ts.append(time.perf_counter() - t1)
         med = sorted(ts)[1]
         err = [float((pred[s][:1].cpu() - ref[s]).abs().max()) for s in range(4)]
+        from lwsnet_amd.metrics import error_3px
+        e3 = error_3px(pred[3][:1].cpu().numpy(), np.maximum(ref[3].numpy(), 1e-3), 192)   # finetune.py:212-219, oracle as GT
         cpu = {"value": round(1.0 / med, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"3 forwards of 1 pair {H}x{W}, median, after probing 8/16/32/64 threads (host has {ncpu} logical "
                          f"CPUs); literal oracle on torch-CPU {torch.__version__} (Paddle-CPU stand-in)",
-               "max_abs_vs_gpu_per_stage": [round(e, 6) for e in err]}
+               "max_abs_vs_gpu_per_stage": [round(e, 6) for e in err], "err_3px_stage4_vs_oracle": e3}
 
     pairs = world * B * args.steps
     out = {
