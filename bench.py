@@ -99,6 +99,12 @@ def main():
     gathered = [torch.empty((B, 1, H, W), device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     counter = [0]
+    pending = [None]
+
+    def gather(pred):
+        # the ONE collective of the path: stage-4 maps -> rank 0.  Asynchronous: RCCL runs it on its own stream behind
+        # this step's kernels, so it overlaps with the next step; the last one is waited for before the clock stops.
+        pending[0] = dist.gather(pred[3], gathered, dst=0, async_op=True)
 
     def step():
         i = counter[0] % S
@@ -106,12 +112,12 @@ def main():
         if S == 1:
             pred = models[0](left, right)
             if world > 1:
-                dist.gather(pred[3], gathered, dst=0)
+                gather(pred)
             return pred
         with torch.cuda.stream(streams[i]):
             pred = models[i](left, right)
             if world > 1:
-                dist.gather(pred[3], gathered, dst=0)
+                gather(pred)
         return pred
 
     for _ in range(args.warmup):
@@ -127,6 +133,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pred = step()
+    if pending[0] is not None:
+        pending[0].wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

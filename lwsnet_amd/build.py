@@ -37,6 +37,7 @@ def needs_build():
 
 
 def build_library(force=False, verbose=False, extra_flags=()):
+    extra_flags = tuple(extra_flags) + tuple(os.environ.get("LWS_EXTRA_FLAGS", "").split())   # e.g. -DLWS_STAMPS (diagnostics)
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()

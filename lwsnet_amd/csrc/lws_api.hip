@@ -440,8 +440,7 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
         } else {
             // the first layer reads the two input tensors separately; the rest runs batched over all N images
             hipStream_t s0 = st;
-            LWS_FE(launch_conv2d_nchw(n.fe[0], imgA, nullptr, a0, nA, H, W, st));
-            if (nB > 0) LWS_FE(launch_conv2d_nchw(n.fe[0], imgB, nullptr, a0 + (size_t)nA * 4 * H2 * W2, nB, H, W, st));
+            LWS_FE(launch_conv2d_nchw(n.fe[0], imgA, nullptr, a0, N, H, W, st, imgB, nA));   // one launch, two input tensors
             LWS_FE(launch_conv2d_nchw(n.fe[1], a0, nullptr, o, N, H2, W2, st));
             LWS_FE(launch_conv2d_nchw(n.fe[2], o, nullptr, a2, N, H2, W2, st));
             LWS_FE(launch_conv2d_nchw(n.fe[3], a2, o, o2, N, H2, W2, st));
@@ -568,10 +567,13 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
             if (rc) return rc;
         }
         if (!fused) {
+            // soft-argmin + rescale + upsample (+ previous stage) in one launch                             :142-148
             ProfScope p(h, LWS_KC_SOFTARGMIN, st);
-            rc = launch_softargmin(cost, low, B, D, hh, ww, start, st);                                      // :142,151
+            rc = launch_softargmin_upsample(cost, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], nullptr, B, D, hh, ww,
+                                            H, W, start, st);
+            if (rc) return rc;
+            continue;
         }
-        if (rc) return rc;
         {
             ProfScope p(h, LWS_KC_UPSAMPLE, st);
             rc = launch_upsample_add(low, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], B, hh, ww, H, W, st);   // :145-156

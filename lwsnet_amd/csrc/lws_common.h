@@ -121,6 +121,8 @@ int launch_volume_l1_warp(const float *L, const float *R, const float *prev, flo
 int launch_softargmin(const float *cost, float *low, int B, int D, int h, int w, float start, hipStream_t st);
 int launch_upsample_add(const float *low, const float *prev, float *out, int B, int h, int w, int H, int W,
                         hipStream_t st);
+int launch_softargmin_upsample(const float *cost, const float *prev, float *out, float *low_out, int B, int D, int h,
+                               int w, int H, int W, float start, hipStream_t st);
 
 // conv3d stack pieces; activations are channels-last [B,D,h,w,C3]
 int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int B, int D, int h, int w,
@@ -132,7 +134,7 @@ int launch_conv3d_last(const Stage3d &s, const float *act_in, const float *cost_
 
 // 2D networks (lws_conv2d.hip)
 int launch_conv2d_nchw(const Conv2dLayer &l, const float *in, const float *res, float *out, int N, int H, int W,
-                       hipStream_t st);
+                       hipStream_t st, const float *in2 = nullptr, int n1 = 0);
 int launch_ref_first(const float *in, int cin, const float *w, float *out, int B, int H, int W, hipStream_t st);
 int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, int W, hipStream_t st);
 int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, float *out, int B, int H, int W,

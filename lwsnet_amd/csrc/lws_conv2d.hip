@@ -34,12 +34,15 @@ __device__ __forceinline__ float f4c(const float4 &v, int j) { return j == 0 ? v
 // Epilogue: BatchNorm (optional) -> + residual (optional) -> ReLU (optional).
 // =============================================================================================
 template <int CIN, int COUT, bool TRANSPOSED>
-__global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ in, const float *__restrict__ wgt,
+__global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ in, const float *__restrict__ in2, int n1,
+                                                     const float *__restrict__ wgt,
                                                      const float *__restrict__ bn_s, const float *__restrict__ bn_t,
                                                      const float *__restrict__ res, float *__restrict__ out, int H,
                                                      int W, int Ho, int Wo, int stride, int pad, int dil, int relu,
                                                      int RH, int RW, int RWp)
 {
+    // images [0, n1) come from `in`, images [n1, N) from `in2` (left and right inputs of the first layer are two
+    // separate caller tensors); the output batch is contiguous
     constexpr int CPT = COUT / 4;
     extern __shared__ float sIn[];   // [CIN][RH][RWp]
     const int b = blockIdx.z;
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ i
     const int ry0 = TRANSPOSED ? ((oy0 - 1) >> 1) : oy0 * stride - pad;
     const int rx0 = TRANSPOSED ? ((ox0 - 1) >> 1) : ox0 * stride - pad;
     const int plane = H * W, oplane = Ho * Wo;
-    const float *inb = in + (int64_t)b * CIN * plane;
+    const float *inb = b < n1 ? in + (int64_t)b * CIN * plane : in2 + (int64_t)(b - n1) * CIN * plane;
     // region positions are decoded once per thread (<= 2 positions: RH*RW <= 19*19), then all CIN planes of a
     // position are loaded back to back (unconditional clamped loads, masked afterwards)
     const int rsz = RH * RW;
@@ -112,23 +115,27 @@ __global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ i
 }
 
 template <int CIN, int COUT, bool TR>
-static int conv2d_launch(const Conv2dLayer &l, const float *in, const float *res, float *out, int N, int H, int W,
-                         int Ho, int Wo, hipStream_t st)
+static int conv2d_launch(const Conv2dLayer &l, const float *in, const float *in2, int n1, const float *res, float *out,
+                         int N, int H, int W, int Ho, int Wo, hipStream_t st)
 {
     const int RH = TR ? 6 : 7 * l.stride + 2 * l.dil + 1, RW = RH;
     const int RWp = RW | 1;                                       // odd row stride
     const size_t lds = (size_t)CIN * RH * RWp * sizeof(float);
     dim3 grid(cdiv(Wo, 8), cdiv(Ho, 8), N), block(256);
-    hipLaunchKernelGGL((k_conv2d_nchw<CIN, COUT, TR>), grid, block, lds, st, in, l.w, l.bn_s, l.bn_t, res, out, H, W, Ho,
-                       Wo, l.stride, l.pad, l.dil, l.relu ? 1 : 0, RH, RW, RWp);
+    hipLaunchKernelGGL((k_conv2d_nchw<CIN, COUT, TR>), grid, block, lds, st, in, in2, n1, l.w, l.bn_s, l.bn_t, res, out, H,
+                       W, Ho, Wo, l.stride, l.pad, l.dil, l.relu ? 1 : 0, RH, RW, RWp);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
 
-// N images [N,cin,H,W] -> [N,cout,Ho,Wo]
+// N images [N,cin,H,W] -> [N,cout,Ho,Wo]; if in2 != nullptr the first n1 images are read from `in`, the rest from `in2`
 int launch_conv2d_nchw(const Conv2dLayer &l, const float *in, const float *res, float *out, int N, int H, int W,
-                       hipStream_t st)
+                       hipStream_t st, const float *in2, int n1)
 {
+    if (in2 == nullptr) {
+        in2 = in;
+        n1 = N;
+    }
     int Ho, Wo;
     if (l.transposed) {
         Ho = 2 * H;
@@ -139,7 +146,7 @@ int launch_conv2d_nchw(const Conv2dLayer &l, const float *in, const float *res, 
     }
 #define LWS_C2D(CI, CO, TR)                                   \
     if (l.cin == CI && l.cout == CO && l.transposed == TR)    \
-        return conv2d_launch<CI, CO, TR>(l, in, res, out, N, H, W, Ho, Wo, st);
+        return conv2d_launch<CI, CO, TR>(l, in, in2, n1, res, out, N, H, W, Ho, Wo, st);
     LWS_C2D(3, 4, false) LWS_C2D(4, 8, false) LWS_C2D(8, 4, false) LWS_C2D(8, 16, false) LWS_C2D(16, 16, false)
     LWS_C2D(16, 16, true) LWS_C2D(16, 8, true) LWS_C2D(8, 8, false)
 #undef LWS_C2D

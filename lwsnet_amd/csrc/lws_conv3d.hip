@@ -23,6 +23,24 @@ namespace lws {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+#ifdef LWS_STAMPS   // diagnostic build only: per-workgroup s_memtime stamps of k_conv3d_mid16 phases
+__device__ unsigned long long g_stamps[4096 * 8];
+#define LWS_STAMP(i)                                                                       \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        unsigned long long t_;                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] = t_; \
+    } while (0)
+extern "C" int lws_debug_read_stamps(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#else
+#define LWS_STAMP(i) do {} while (0)
+#endif
+
 __device__ __forceinline__ float bn_relu(float x, float s, float t) { return fmaxf(fmaf(x, s, t), 0.0f); }
 
 // compile-time component select (j is always a constant after unrolling)
@@ -172,6 +190,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
     const int b = blockIdx.y;
     const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * C3;
+    LWS_STAMP(0);
 
     // ---- stage the halo tile: one item = (voxel, 16-channel group) = 64 contiguous bytes.  All global loads
     //      of a thread are issued first (SITER x 4 float4 in flight), then transposed 4x4 and written to LDS.
@@ -216,6 +235,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) wbuf[0][q][mt] = wp[(q * MT + mt) * 64];
     __syncthreads();
+    LWS_STAMP(1);
 
     floatx4 acc[RW][MTW];
 #pragma unroll
@@ -294,6 +314,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
         }
     }
 
+    LWS_STAMP(2);
     // ---- epilogue: D[i][j]: row i = 4*(lane>>4) + reg = output channel in the tile, col j = lane&15 = voxel.
     //      Apply the NEXT layer's BatchNorm + ReLU and store 4 consecutive channels of one voxel (16 B).
     float *outb = out + (int64_t)b * D * h * w * C3;
@@ -318,6 +339,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
             }
         }
     }
+    LWS_STAMP(3);
 }
 
 // =============================================================================================
