@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <functional>
+#include <stdlib.h>
 
 #include "lws_common.h"
 
@@ -408,18 +409,33 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
         rc = (call);                                   \
     }                                                  \
     if (rc) return rc;
-    // layers up to the 1/8 map (dres0, dres1, hourglass conv1..conv4) for images [i0, i0+cnt) on stream s
-    auto head = [&](hipStream_t s, const float *img, int i0, int cnt) -> int {
+    // layers up to the 1/8 map (dres0, dres1, hourglass conv1..conv4) for `cnt` images starting at batch index i0 on
+    // stream s; images [0, n1) are read from img, the rest from img2.  LWS_PAIR=1 runs consecutive layers pairwise in
+    // one launch (k_conv2d_pair, bit-identical).  Measured r01 on MI355X: 22.4 us per pair vs 2 x 14.4 us per layer in
+    // isolation, but 1429 vs 1474 pairs/s end to end at B = 1 (and worse at B = 8): the halo recompute of the first
+    // layer costs more than the saved launch, so one kernel per layer stays the default.
+    static const bool no_pair = [] {
+        const char *e = getenv("LWS_PAIR");
+        return !(e != nullptr && atoi(e) != 0);
+    }();
+    auto head = [&](hipStream_t s, const float *img, const float *img2, int n1, int i0, int cnt) -> int {
         hipStream_t st = s;   // (the profiling macro names the stream `st`)
         const size_t q2 = (size_t)i0 * H2 * W2, q4 = (size_t)i0 * H4 * W4, q8 = (size_t)i0 * H8 * W8;
-        LWS_FE(launch_conv2d_nchw(n.fe[0], img, nullptr, a0 + 4 * q2, cnt, H, W, st));                      // dres0.0
-        LWS_FE(launch_conv2d_nchw(n.fe[1], a0 + 4 * q2, nullptr, o + 8 * q2, cnt, H2, W2, st));             // dres0.2
-        LWS_FE(launch_conv2d_nchw(n.fe[2], o + 8 * q2, nullptr, a2 + 4 * q2, cnt, H2, W2, st));             // dres1.0
-        LWS_FE(launch_conv2d_nchw(n.fe[3], a2 + 4 * q2, o + 8 * q2, o2 + 8 * q2, cnt, H2, W2, st));         // dres1.2 + o (:179)
-        LWS_FE(launch_conv2d_nchw(n.fe[4], o2 + 8 * q2, nullptr, c1 + 16 * q4, cnt, H2, W2, st));           // conv1 (1/4)
-        LWS_FE(launch_conv2d_nchw(n.fe[5], c1 + 16 * q4, nullptr, pre + 16 * q4, cnt, H4, W4, st));         // conv2 -> pre
-        LWS_FE(launch_conv2d_nchw(n.fe[6], pre + 16 * q4, nullptr, c3 + 16 * q8, cnt, H4, W4, st));         // conv3 (1/8)
-        LWS_FE(launch_conv2d_nchw(n.fe[7], c3 + 16 * q8, nullptr, f8 + 16 * q8, cnt, H8, W8, st));          // conv4 -> f8
+        if (no_pair) {
+            LWS_FE(launch_conv2d_nchw(n.fe[0], img, nullptr, a0 + 4 * q2, cnt, H, W, st, img2, n1));            // dres0.0
+            LWS_FE(launch_conv2d_nchw(n.fe[1], a0 + 4 * q2, nullptr, o + 8 * q2, cnt, H2, W2, st));             // dres0.2
+            LWS_FE(launch_conv2d_nchw(n.fe[2], o + 8 * q2, nullptr, a2 + 4 * q2, cnt, H2, W2, st));             // dres1.0
+            LWS_FE(launch_conv2d_nchw(n.fe[3], a2 + 4 * q2, o + 8 * q2, o2 + 8 * q2, cnt, H2, W2, st));         // dres1.2 + o (:179)
+            LWS_FE(launch_conv2d_nchw(n.fe[4], o2 + 8 * q2, nullptr, c1 + 16 * q4, cnt, H2, W2, st));           // conv1 (1/4)
+            LWS_FE(launch_conv2d_nchw(n.fe[5], c1 + 16 * q4, nullptr, pre + 16 * q4, cnt, H4, W4, st));         // conv2 -> pre
+            LWS_FE(launch_conv2d_nchw(n.fe[6], pre + 16 * q4, nullptr, c3 + 16 * q8, cnt, H4, W4, st));         // conv3 (1/8)
+            LWS_FE(launch_conv2d_nchw(n.fe[7], c3 + 16 * q8, nullptr, f8 + 16 * q8, cnt, H8, W8, st));          // conv4 -> f8
+            return LWS_OK;
+        }
+        LWS_FE(launch_conv2d_pair(n.fe[0], n.fe[1], img, nullptr, o + 8 * q2, cnt, H, W, st, img2, n1));         // dres0
+        LWS_FE(launch_conv2d_pair(n.fe[2], n.fe[3], o + 8 * q2, o + 8 * q2, o2 + 8 * q2, cnt, H2, W2, st));      // dres1 + o (:179)
+        LWS_FE(launch_conv2d_pair(n.fe[4], n.fe[5], o2 + 8 * q2, nullptr, pre + 16 * q4, cnt, H2, W2, st));      // conv1, conv2 -> pre
+        LWS_FE(launch_conv2d_pair(n.fe[6], n.fe[7], pre + 16 * q4, nullptr, f8 + 16 * q8, cnt, H4, W4, st));     // conv3, conv4 -> f8
         return LWS_OK;
     };
     if (tail != nullptr && nB >= 4 && h->side2 != nullptr) {
@@ -427,29 +443,15 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
         // layers run on a second side stream and join before f8 is consumed (measured r01: +4 % at B = 8, but
         // -11 % at B = 1, where the two half-size launches only add dispatch overhead: there they stay batched)
         LWS_HIP(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
-        rc = head(h->side2, imgB, nA, nB);
+        rc = head(h->side2, imgB, nullptr, nB, nA, nB);
         if (rc) return rc;
         LWS_HIP(hipEventRecord(h->ev_right, h->side2));
-        rc = head(st, imgA, 0, nA);
+        rc = head(st, imgA, nullptr, nA, 0, nA);
         if (rc) return rc;
         LWS_HIP(hipStreamWaitEvent(st, h->ev_right, 0));
     } else {
-        if (nB > 0 && imgB == imgA + (size_t)nA * 3 * H * W) {
-            rc = head(st, imgA, 0, nA + nB);            // one contiguous batch
-            if (rc) return rc;
-        } else {
-            // the first layer reads the two input tensors separately; the rest runs batched over all N images
-            hipStream_t s0 = st;
-            LWS_FE(launch_conv2d_nchw(n.fe[0], imgA, nullptr, a0, N, H, W, st, imgB, nA));   // one launch, two input tensors
-            LWS_FE(launch_conv2d_nchw(n.fe[1], a0, nullptr, o, N, H2, W2, st));
-            LWS_FE(launch_conv2d_nchw(n.fe[2], o, nullptr, a2, N, H2, W2, st));
-            LWS_FE(launch_conv2d_nchw(n.fe[3], a2, o, o2, N, H2, W2, st));
-            LWS_FE(launch_conv2d_nchw(n.fe[4], o2, nullptr, c1, N, H2, W2, st));
-            LWS_FE(launch_conv2d_nchw(n.fe[5], c1, nullptr, pre, N, H4, W4, st));
-            LWS_FE(launch_conv2d_nchw(n.fe[6], pre, nullptr, c3, N, H4, W4, st));
-            LWS_FE(launch_conv2d_nchw(n.fe[7], c3, nullptr, f8, N, H8, W8, st));
-            (void)s0;
-        }
+        rc = head(st, imgA, nB > 0 ? imgB : nullptr, nA, 0, N);   // one batch over all N images (two input tensors)
+        if (rc) return rc;
     }
 #undef LWS_FE
     if (tail != nullptr) return LWS_OK;

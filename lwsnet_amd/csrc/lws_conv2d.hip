@@ -155,6 +155,158 @@ int launch_conv2d_nchw(const Conv2dLayer &l, const float *in, const float *res, 
 }
 
 // =============================================================================================
+// Two chained feature-extractor layers in one launch: A (3x3, stride sA, dilation dA, BN, ReLU?) followed by B (3x3,
+// stride 1, dilation dB, BN?, + residual?, ReLU?).  The workgroup owns an 8 x 8 tile of B's output; A is evaluated on
+// the (8 + 2 dB)^2 region B needs (its values outside A's output map are B's zero padding) and kept in LDS, so the
+// intermediate map never goes to HBM and one launch (~7 us of fixed cost at batch 1) disappears.  Every layer keeps
+// its own arithmetic (same fma chains), so the result is bit-identical to running the two kernels back to back.
+// =============================================================================================
+template <int CIN, int CM, int COUT>
+__global__ __launch_bounds__(256) void k_conv2d_pair(const float *__restrict__ in, const float *__restrict__ in2, int n1,
+                                                     const float *__restrict__ wA, const float *__restrict__ sA_,
+                                                     const float *__restrict__ tA_, int reluA,
+                                                     const float *__restrict__ wB, const float *__restrict__ sB_,
+                                                     const float *__restrict__ tB_, const float *__restrict__ res,
+                                                     int reluB, float *__restrict__ out, int H, int W, int HA, int WA,
+                                                     int strideA, int padA, int dilA, int dilB, int RH, int RWp, int MR,
+                                                     int MRp)
+{
+    constexpr int CPA = CM / 4, CPB = COUT / 4;
+    extern __shared__ float smem[];
+    float *sIn = smem;                       // [CIN][RH][RWp]
+    float *sMid = smem + CIN * RH * RWp;     // [CM][MR][MRp]
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ox0 = blockIdx.x * 8, oy0 = blockIdx.y * 8;
+    const int my0 = oy0 - dilB, mx0 = ox0 - dilB;                 // origin of the intermediate region (A-output coords)
+    const int iy0 = my0 * strideA - padA, ix0 = mx0 * strideA - padA;
+    const int plane = H * W;
+    const float *inb = b < n1 ? in + (int64_t)b * CIN * plane : in2 + (int64_t)(b - n1) * CIN * plane;
+    // phase 1: input region
+    const int rsz = RH * RH;
+    for (int r = tid; r < rsz; r += 256) {
+        const int ry = r / RH, rx = r - ry * RH;
+        const int gy = iy0 + ry, gx = ix0 + rx;
+        const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const float *src = inb + (ok ? gy * W + gx : 0);
+        float v[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) v[ci] = src[ci * plane];
+        float *dst = sIn + ry * RWp + rx;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) dst[ci * RH * RWp] = ok ? v[ci] : 0.0f;
+    }
+    __syncthreads();
+    // phase 2: layer A on the MR x MR region; wave = output-channel group of A
+    {
+        const int coA = wave * CPA;
+        const int npx = MR * MR;
+        for (int p = lane; p < npx; p += 64) {
+            const int my = p / MR, mx = p - my * MR;
+            const int ay = my0 + my, ax = mx0 + mx;
+            const bool valid = ay >= 0 && ay < HA && ax >= 0 && ax < WA;
+            float acc[CPA];
+#pragma unroll
+            for (int c = 0; c < CPA; ++c) acc[c] = 0.0f;
+#pragma unroll 3
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const float *pp = sIn + (my * strideA + kh * dilA) * RWp + mx * strideA + kw * dilA;
+                const float *w = wA + tap * CIN * CM + coA;
+                float v[CIN];
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) v[ci] = pp[ci * RH * RWp];
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                    for (int c = 0; c < CPA; ++c) acc[c] = fmaf(v[ci], w[ci * CM + c], acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < CPA; ++c) {
+                float v = fmaf(acc[c], sA_[coA + c], tA_[coA + c]);
+                if (reluA) v = fmaxf(v, 0.0f);
+                sMid[((coA + c) * MR + my) * MRp + mx] = valid ? v : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    // phase 3: layer B on the 8 x 8 tile; wave = output-channel group of B, lane = pixel
+    const int tx = lane & 7, ty = lane >> 3;
+    const int ox = ox0 + tx, oy = oy0 + ty;
+    if (ox >= WA || oy >= HA) return;
+    const int coB = wave * CPB;
+    float acc[CPB];
+#pragma unroll
+    for (int c = 0; c < CPB; ++c) acc[c] = 0.0f;
+#pragma unroll 3
+    for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const float *pp = sMid + (ty + kh * dilB) * MRp + tx + kw * dilB;
+        const float *w = wB + tap * CM * COUT + coB;
+        float v[CM];
+#pragma unroll
+        for (int ci = 0; ci < CM; ++ci) v[ci] = pp[ci * MR * MRp];
+#pragma unroll
+        for (int ci = 0; ci < CM; ++ci)
+#pragma unroll
+            for (int c = 0; c < CPB; ++c) acc[c] = fmaf(v[ci], w[ci * COUT + c], acc[c]);
+    }
+    const int oplane = HA * WA;
+    const int64_t o = ((int64_t)b * COUT + coB) * oplane + oy * WA + ox;
+#pragma unroll
+    for (int c = 0; c < CPB; ++c) {
+        float v = acc[c];
+        if (sB_ != nullptr) v = fmaf(v, sB_[coB + c], tB_[coB + c]);
+        if (res != nullptr) v = v + res[o + (int64_t)c * oplane];
+        if (reluB) v = fmaxf(v, 0.0f);
+        out[o + (int64_t)c * oplane] = v;
+    }
+}
+
+template <int CIN, int CM, int COUT>
+static int conv2d_pair_launch(const Conv2dLayer &a, const Conv2dLayer &b, const float *in, const float *in2, int n1,
+                              const float *res, float *out, int N, int H, int W, int HA, int WA, hipStream_t st)
+{
+    const int MR = 8 + 2 * b.dil, MRp = MR | 1;
+    const int RH = (MR - 1) * a.stride + 2 * a.dil + 1, RWp = RH | 1;
+    const size_t lds = ((size_t)CIN * RH * RWp + (size_t)CM * MR * MRp) * sizeof(float);
+    static size_t attr_lds = 0;
+    if (lds > 48 * 1024 && lds > attr_lds) {
+        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv2d_pair<CIN, CM, COUT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    dim3 grid(cdiv(WA, 8), cdiv(HA, 8), N), block(256);
+    hipLaunchKernelGGL((k_conv2d_pair<CIN, CM, COUT>), grid, block, lds, st, in, in2, n1, a.w, a.bn_s, a.bn_t,
+                       a.relu ? 1 : 0, b.w, b.bn_s, b.bn_t, res, b.relu ? 1 : 0, out, H, W, HA, WA, a.stride, a.pad, a.dil,
+                       b.dil, RH, RWp, MR, MRp);
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+// layer a (conv, BN) then layer b (conv stride 1, pad == dil) on N images [N,a.cin,H,W] -> [N,b.cout,HA,WA]
+int launch_conv2d_pair(const Conv2dLayer &a, const Conv2dLayer &b, const float *in, const float *res, float *out, int N,
+                       int H, int W, hipStream_t st, const float *in2, int n1)
+{
+    if (a.transposed || b.transposed || b.stride != 1 || b.pad != b.dil || a.bn_s == nullptr || b.cin != a.cout) {
+        set_error("conv2d_pair: unsupported layer pair");
+        return LWS_ERR_INVALID;
+    }
+    if (in2 == nullptr) {
+        in2 = in;
+        n1 = N;
+    }
+    const int HA = (H + 2 * a.pad - 2 * a.dil - 1) / a.stride + 1, WA = (W + 2 * a.pad - 2 * a.dil - 1) / a.stride + 1;
+#define LWS_C2P(CI, CMID, CO)                                  \
+    if (a.cin == CI && a.cout == CMID && b.cout == CO)         \
+        return conv2d_pair_launch<CI, CMID, CO>(a, b, in, in2, n1, res, out, N, H, W, HA, WA, st);
+    LWS_C2P(3, 4, 8) LWS_C2P(8, 4, 8) LWS_C2P(8, 16, 16) LWS_C2P(16, 16, 16)
+#undef LWS_C2P
+    set_error("conv2d_pair: unsupported channels %d -> %d -> %d", a.cin, a.cout, b.cout);
+    return LWS_ERR_INVALID;
+}
+
+// =============================================================================================
 // Refinement, first convolution: NCHW image (3 ch) or disparity (1 ch) -> channels-last [B,H,W,32], 3x3 pad 1,
 // no BatchNorm (submodules.py:284-291).  4 threads per pixel, 8 output channels each: a wave stores 16 whole lines.
 // =============================================================================================
