@@ -35,6 +35,30 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Diagnostic builds only (LWS_EXTRA_FLAGS=-DLWS_STAMPS; tools/stamps.py): every workgroup stores s_memtime stamps of
+// its phases in a per-translation-unit buffer; the shipped library compiles LWS_STAMP to nothing.
+#ifdef LWS_STAMPS
+#define LWS_DEFINE_STAMPS(tu)                                                                                      \
+    __device__ unsigned long long g_stamps_##tu[4096 * 8];                                                         \
+    static __device__ __forceinline__ void stamp_(int i)                                                           \
+    {                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        unsigned long long t_;                                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                       \
+        if (threadIdx.x == 0 && threadIdx.y == 0 && bid < 4096) g_stamps_##tu[bid * 8 + i] = t_;                   \
+    }                                                                                                              \
+    extern "C" int lws_debug_read_stamps_##tu(unsigned long long *out, int n)                                      \
+    {                                                                                                              \
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_##tu), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1; \
+    }
+#define LWS_STAMP(i) stamp_(i)
+#else
+#define LWS_DEFINE_STAMPS(tu)
+#define LWS_STAMP(i) do {} while (0)
+#endif
+
 // One BatchNorm3D -> ReLU -> Conv3D layer, device side.
 struct Conv3dLayer {
     int cin = 0, cout = 0;

@@ -22,6 +22,8 @@ namespace lws {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+LWS_DEFINE_STAMPS(conv2d)
+
 __device__ __forceinline__ float bn_relu2(float x, float s, float t) { return fmaxf(fmaf(x, s, t), 0.0f); }
 __device__ __forceinline__ float f4c(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
@@ -413,6 +415,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RefTile t = ref_tile(dil, nbx, nby);
     const float *inb = in + (int64_t)t.b * H * W * 32;
+    LWS_STAMP(0);
 
     const int c4 = tid & 7;
     const float4 s4 = *reinterpret_cast<const float4 *>(bn_s + c4 * 4);
@@ -449,6 +452,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
         if (hp < NPX) sA[c4 * DWS_SA + hp] = v;
     }
     __syncthreads();
+    LWS_STAMP(1);
 
     // 2. depthwise: tile pixel p = (tid >> 3) + 32 i  ->  row (tid >> 7) + 2 i, column (tid >> 3) & 15
     {
@@ -477,6 +481,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
         }
     }
     __syncthreads();
+    LWS_STAMP(2);
 
     // 3. pointwise MFMA: wave handles tile rows 2*wave, 2*wave+1 x both output-channel tiles
     const int n = lane & 15, g = lane >> 4;
@@ -500,6 +505,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
                 for (int mt = 0; mt < 2; ++mt)
                     acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(aw[q][mt], j), f4c(bv[r][q], j), acc[r][mt], 0, 0, 0);
 
+    LWS_STAMP(3);
     // 4. store: lane (n, g) holds channels 16mt + 4g .. +3 of pixel (row, n)
     float *outb = out + (int64_t)t.b * H * W * 32;
     const int gx = t.X0 + n * dil;
@@ -514,6 +520,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
                     make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
         }
     }
+    LWS_STAMP(4);
 }
 
 // =============================================================================================

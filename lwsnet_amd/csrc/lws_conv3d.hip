@@ -23,23 +23,7 @@ namespace lws {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-#ifdef LWS_STAMPS   // diagnostic build only: per-workgroup s_memtime stamps of k_conv3d_mid16 phases
-__device__ unsigned long long g_stamps[4096 * 8];
-#define LWS_STAMP(i)                                                                       \
-    do {                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-        unsigned long long t_;                                                             \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] = t_; \
-    } while (0)
-extern "C" int lws_debug_read_stamps(unsigned long long *out, int n)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
-}
-#else
-#define LWS_STAMP(i) do {} while (0)
-#endif
+LWS_DEFINE_STAMPS(conv3d)
 
 __device__ __forceinline__ float bn_relu(float x, float s, float t) { return fmaxf(fmaf(x, s, t), 0.0f); }
 
@@ -388,6 +372,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
     const int b = blockIdx.y;
     const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * 8;
+    LWS_STAMP(0);
 
     // 72 A fragments of this lane as 18 float4 ([step/4][lane][4]): 18 wide loads instead of 72 dword loads
     float wa[72];
@@ -400,21 +385,36 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
         wa[4 * s4 + 3] = v.w;
     }
 
-    // ---- stage: one item = half a voxel (4 channels, 16 B); scatter into 4 channel planes ----
-    for (int it = tid; it < Cfg::NVOX * 2; it += 256) {
-        const int half = it & 1, v = it >> 1;
-        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
-        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        const bool ok = gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        float4 c = *reinterpret_cast<const float4 *>(inb + (ok ? (((int64_t)gd * h + gy) * w + gx) * 8 + half * 4 : 0));
-        if (!ok) c = make_float4(0.f, 0.f, 0.f, 0.f);
-        float *dst = lds + (half * 4) * PS + v;
-        dst[0] = c.x;
-        dst[PS] = c.y;
-        dst[2 * PS] = c.z;
-        dst[3 * PS] = c.w;
+    // ---- stage: one item = half a voxel (4 channels, 16 B); scatter into 4 channel planes.  Static trip count:
+    //      all global loads of a thread are issued before the first LDS write (one memory round trip, not SITER).
+    {
+        constexpr int ITEMS = Cfg::NVOX * 2, SITER = (ITEMS + 255) / 256;
+        float4 c[SITER];
+        bool okv[SITER];
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * 256;
+            const int half = it & 1, v = it >> 1;
+            const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+            const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            okv[i] = it < ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            c[i] = *reinterpret_cast<const float4 *>(inb + (okv[i] ? (((int64_t)gd * h + gy) * w + gx) * 8 + half * 4 : 0));
+        }
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * 256;
+            if (it < ITEMS) {
+                const float4 v4 = okv[i] ? c[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float *dst = lds + ((it & 1) * 4) * PS + (it >> 1);
+                dst[0] = v4.x;
+                dst[PS] = v4.y;
+                dst[2 * PS] = v4.z;
+                dst[3 * PS] = v4.w;
+            }
+        }
     }
     __syncthreads();
+    LWS_STAMP(1);
 
     floatx4 acc[RW];
     int rbase[RW];
@@ -443,6 +443,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
                     }
                 }
 
+    LWS_STAMP(2);
     // ---- epilogue: row i = 4*(lane>>4) + reg -> xpar = (lane>>4)>>1, cout = 4*((lane>>4)&1) + reg ----
     float *outb = out + (int64_t)b * D * h * w * 8;
     const int xpar = g >> 1, cb = 4 * (g & 1);
@@ -462,6 +463,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
             *reinterpret_cast<float4 *>(outb + (((int64_t)gd * h + gy) * w + gx) * 8 + cb) = v;
         }
     }
+    LWS_STAMP(3);
 }
 
 // =============================================================================================

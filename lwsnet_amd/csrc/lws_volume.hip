@@ -25,10 +25,23 @@ __global__ __launch_bounds__(256) void k_volume_l1_shift(const float *__restrict
     const int span = 64 + D - 1;
     const int64_t plane = (int64_t)h * w;
     const float *Rb = R + (int64_t)b * C * plane + (int64_t)y * w;
-    for (int i = ty * 64 + tx; i < C * span; i += 256) {
-        int c = i / span, p = i - c * span;
-        int x = x0 - (D - 1) + p;
-        sR[i] = (x >= 0 && x < w) ? Rb[(int64_t)c * plane + x] : 0.0f;
+    // wave ty stages channels ty, ty+4, ...; positions p = tx and tx + 64 (span <= 127): all C/2 loads of a thread are
+    // unconditional (clamped) and in flight together
+    {
+        const int xa = x0 - (D - 1) + tx, xb = xa + 64;
+        const bool oka = xa >= 0 && xa < w, okb = tx + 64 < span && xb >= 0 && xb < w;
+        float va[C / 4], vb[C / 4];
+#pragma unroll
+        for (int j = 0; j < C / 4; ++j) {
+            const float *rc = Rb + (int64_t)(ty + 4 * j) * plane;
+            va[j] = rc[oka ? xa : 0];
+            vb[j] = rc[okb ? xb : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < C / 4; ++j) {
+            sR[(ty + 4 * j) * span + tx] = oka ? va[j] : 0.0f;
+            if (tx + 64 < span) sR[(ty + 4 * j) * span + tx + 64] = okb ? vb[j] : 0.0f;
+        }
     }
     __syncthreads();
     const int x = x0 + tx;
