@@ -520,7 +520,6 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
                     make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
         }
     }
-    LWS_STAMP(4);
 }
 
 // =============================================================================================
@@ -540,6 +539,7 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RefTile t = ref_tile(dil, nbx, nby, TY);
     const int n = lane & 15, g = lane >> 4;
+    LWS_STAMP(4);
 
     // stage: item = (tensor, halo pixel, 16-channel group) = 64 bytes
     constexpr int ITEMS = 2 * NPX * 2, SITER = (ITEMS + 255) / 256;
@@ -589,6 +589,7 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) wbuf[0][qq][mt] = wp[(qq * 2 + mt) * 64];
     __syncthreads();
+    LWS_STAMP(5);
 
     floatx4 acc[RW][2];
 #pragma unroll
@@ -632,6 +633,7 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) wbuf[0][qq][mt] = wbuf[1][qq][mt];
     }
+    LWS_STAMP(6);
     float *outb = out + (int64_t)t.b * H * W * 32;
     const int gx = t.X0 + n * dil;
 #pragma unroll
@@ -645,6 +647,7 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
                     make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
         }
     }
+    LWS_STAMP(7);
 }
 
 // =============================================================================================

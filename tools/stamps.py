@@ -13,7 +13,7 @@ m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
 lib = ctypes.CDLL(_lib.LIB_PATH)
 what = sys.argv[1] if len(sys.argv) > 1 else "0"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-if what == "dws":           # last k_ref_dws launch of the refinement (dilation 1)
+if what in ("dws", "conv64"):   # last k_ref_dws launch of the refinement (dilation 1) / the k_ref_conv64 launch
     TU = "conv2d"
     left = torch.randn((B, 3, 256, 512), device=dev)
     p3 = torch.rand((B, 1, 256, 512), device=dev) * 100
@@ -31,11 +31,12 @@ torch.cuda.synchronize()
 n = 4096 * 8
 buf = (ctypes.c_ulonglong * n)()
 assert getattr(lib, "lws_debug_read_stamps_" + TU)(buf, n) == 0
-NS = 5 if what == "dws" else 4
-s = np.array(buf, dtype=np.int64).reshape(-1, 8)[:, :NS]
+NS = 4
+raw = np.array(buf, dtype=np.int64).reshape(-1, 8)
+s = raw[:, 4:8] if what == "conv64" else raw[:, :NS]
 s = s[s[:, 0] > 0]
 print(f"{what} B={B}: workgroups with stamps: {len(s)}")
-phases = ((0, 1, "staging"), (1, 2, "depthwise"), (2, 3, "pointwise"), (3, 4, "store"), (0, 4, "total")) if what == "dws" else \
+phases = ((0, 1, "staging"), (1, 2, "depthwise"), (2, 3, "pointwise"), (0, 3, "total")) if what == "dws" else \
     ((0, 1, "staging"), (1, 2, "mfma loop"), (2, 3, "epilogue"), (0, 3, "total"))
 for a, b, name in phases:
     d = s[:, b] - s[:, a]
