@@ -151,8 +151,9 @@ int launch_softargmin_upsample(const float *cost, const float *prev, float *out,
 // conv3d stack pieces; activations are channels-last [B,D,h,w,C3]
 int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int B, int D, int h, int w,
                         hipStream_t st);
+// e0/e1 (optional, C3 % 16 == 0 only): events stamped with the kernel's own begin / end (hipExtLaunchKernelGGL)
 int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *act_out, int B, int D, int h,
-                      int w, hipStream_t st);
+                      int w, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 int launch_conv3d_last(const Stage3d &s, const float *act_in, const float *cost_skip, float *cost_out, int B,
                        int D, int h, int w, hipStream_t st);
 

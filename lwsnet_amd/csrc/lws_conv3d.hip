@@ -14,6 +14,7 @@
 //   k_conv3d_mid16  C3 % 16 == 0     fp32 MFMA implicit GEMM, M = cout tile, N = 16 voxels along x
 //   k_conv3d_mid8   C3 == 8          fp32 MFMA, M = (x parity, cout) so that all 16 MFMA rows work
 //   k_conv3d_last   C3 -> 1 + skip   VALU (K = 27*C3)
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 #include "lws_common.h"
@@ -630,7 +631,7 @@ int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int
 
 template <int C3, int TD, int TY, int WR, int WM>
 static int mid16_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w,
-                        hipStream_t st)
+                        hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     using Cfg = Mid16Cfg<C3, TD, TY, WR, WM>;
     static bool attr_set = false;
@@ -642,9 +643,16 @@ static int mid16_launch(const Stage3d &s, int layer, const float *in, float *out
     const int tiles_x = cdiv(w, 16), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
     block = dim3(Cfg::NT);
-    hipLaunchKernelGGL((k_conv3d_mid16<C3, TD, TY, WR, WM>), grid, block, Cfg::LDS_BYTES, st, in,
-                       reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
-                       s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y);
+    if (e0 != nullptr) {
+        // profiler on: the events carry the kernel's own begin / end timestamps (no dispatch latency in between)
+        hipExtLaunchKernelGGL((k_conv3d_mid16<C3, TD, TY, WR, WM>), grid, block, Cfg::LDS_BYTES, st, e0, e1, 0, in,
+                              reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
+                              s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y);
+    } else {
+        hipLaunchKernelGGL((k_conv3d_mid16<C3, TD, TY, WR, WM>), grid, block, Cfg::LDS_BYTES, st, in,
+                           reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
+                           s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y);
+    }
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -670,7 +678,7 @@ static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out,
 
 // layer = 1 .. layers_3d (the C3 -> C3 convolutions)
 int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *act_out, int B, int D, int h,
-                      int w, hipStream_t st)
+                      int w, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     switch (s.c3) {
         case 8: {
@@ -684,7 +692,7 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
             if (variant == 1 && D >= 9) return mid8_launch<9, 4>(s, layer, act_in, act_out, B, D, h, w, st);
             return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
         }
-        case 16: return mid16_launch<16, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st);
+        case 16: return mid16_launch<16, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
         case 32: {
             // tile/wave-layout variants (LWS_MID16_VARIANT is a development knob; default chosen by measurement)
             static const int variant = [] {
@@ -692,10 +700,10 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
                 return e ? atoi(e) : 0;
             }();
             switch (variant) {
-                case 1: return mid16_launch<32, 3, 4, 4, 2>(s, layer, act_in, act_out, B, D, h, w, st);
-                case 2: return mid16_launch<32, 3, 2, 2, 2>(s, layer, act_in, act_out, B, D, h, w, st);
-                case 3: return mid16_launch<32, 3, 8, 4, 2>(s, layer, act_in, act_out, B, D, h, w, st);
-                default: return mid16_launch<32, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st);
+                case 1: return mid16_launch<32, 3, 4, 4, 2>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
+                case 2: return mid16_launch<32, 3, 2, 2, 2>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
+                case 3: return mid16_launch<32, 3, 8, 4, 2>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
+                default: return mid16_launch<32, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
             }
         }
         default: set_error("conv3d: unsupported channel count %d (8, 16, 32)", s.c3); return LWS_ERR_INVALID;

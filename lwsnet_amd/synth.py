@@ -76,7 +76,8 @@ def make_pair(H, W, index=0):
         return np.where(ok[None], v, 0.0)
 
     right = tap(x0) * (1.0 - lam)[None] + tap(x1) * lam[None]
-    return _normalise(left), _normalise(right), g.astype(np.float32)
+    return (np.ascontiguousarray(_normalise(left)), np.ascontiguousarray(_normalise(right)),
+            np.ascontiguousarray(g, dtype=np.float32))
 
 
 def make_noise_pair(H, W, index=0):
@@ -93,4 +94,4 @@ def make_batch(B, H, W, first_index=0):
         l, r, _ = make_pair(H, W, first_index + i)
         ls.append(l)
         rs.append(r)
-    return np.stack(ls), np.stack(rs)
+    return np.ascontiguousarray(np.stack(ls)), np.ascontiguousarray(np.stack(rs))
