@@ -184,8 +184,9 @@ static hipEvent_t prof_event(lws_ctx *h)
         h->evt_pool.pop_back();
         return e;
     }
+    // timing events never publish data to the host: no system-scope fence when they complete
     hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return nullptr;
     return e;
 }
 
@@ -914,11 +915,11 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     // extractor and the three volume stages, and joins before the rest of the refinement (speed only).
     if (!h->side) {
         LWS_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-        LWS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        LWS_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        for (int i = 0; i < 3; ++i) LWS_HIP(hipEventCreateWithFlags(&h->ev_feat[i], hipEventDisableTiming));
+        LWS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
+        LWS_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
+        for (int i = 0; i < 3; ++i) LWS_HIP(hipEventCreateWithFlags(&h->ev_feat[i], hipEventDisableTiming | hipEventDisableSystemFence));
         LWS_HIP(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
-        LWS_HIP(hipEventCreateWithFlags(&h->ev_right, hipEventDisableTiming));
+        LWS_HIP(hipEventCreateWithFlags(&h->ev_right, hipEventDisableTiming | hipEventDisableSystemFence));
     }
     LWS_HIP(hipEventRecord(h->ev_fork, st));
     LWS_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
