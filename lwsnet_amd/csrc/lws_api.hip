@@ -398,7 +398,7 @@ static void bind_net2d(lws_ctx *h, const Net2dOffsets &o)
 
 // feature_extraction.forward (submodules.py:176-188) on N images; first layer may read two separate inputs
 static int feature_tail(lws_ctx *h, int N, int H, int W, const WsLayout &L, float *f8, float *f4, float *f2,
-                        hipStream_t st, hipEvent_t *ev);
+                        hipStream_t st, hipEvent_t *ev, int part = 3);
 
 // If tail != nullptr only the layers up to the 1/8 map run here (stage 1 needs nothing else); the caller runs
 // feature_tail (conv5, conv6, classif1 -> f4, f2) on the `tail` stream later, overlapped with the volume stages.
@@ -469,9 +469,9 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
 }
 
 // conv5 (-> f4), conv6, classif1 (-> f2), submodules.py:103-107,182-186.  ev (optional): ev[1] recorded after f4,
-// ev[2] after f2, on st.
+// ev[2] after f2, on st.  part: bit 0 = conv5 (f4), bit 1 = conv6 + classif1 (f2).
 static int feature_tail(lws_ctx *h, int N, int H, int W, const WsLayout &L, float *f8, float *f4, float *f2,
-                        hipStream_t st, hipEvent_t *ev)
+                        hipStream_t st, hipEvent_t *ev, int part)
 {
     const Net2d &n = h->net2d;
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
@@ -484,12 +484,16 @@ static int feature_tail(lws_ctx *h, int N, int H, int W, const WsLayout &L, floa
         rc = (call);                                   \
     }                                                  \
     if (rc) return rc;
-    LWS_FE(launch_conv2d_nchw(n.fe[8], f8, pre, f4, N, H8, W8, st));                                        // relu(conv5 + pre) (:103)
-    if (ev != nullptr) LWS_HIP(hipEventRecord(ev[1], st));
-    LWS_FE(launch_conv2d_nchw(n.fe[9], f4, o2, o3, N, H4, W4, st));                                         // conv6 + output (:106,:182)
-    LWS_FE(launch_conv2d_nchw(n.fe[10], o3, nullptr, cls, N, H2, W2, st));                                  // classif1.0
-    LWS_FE(launch_conv2d_nchw(n.fe[11], cls, nullptr, f2, N, H2, W2, st));                                  // classif1.2 -> f2
-    if (ev != nullptr) LWS_HIP(hipEventRecord(ev[2], st));
+    if (part & 1) {
+        LWS_FE(launch_conv2d_nchw(n.fe[8], f8, pre, f4, N, H8, W8, st));                                    // relu(conv5 + pre) (:103)
+        if (ev != nullptr) LWS_HIP(hipEventRecord(ev[1], st));
+    }
+    if (part & 2) {
+        LWS_FE(launch_conv2d_nchw(n.fe[9], f4, o2, o3, N, H4, W4, st));                                     // conv6 + output (:106,:182)
+        LWS_FE(launch_conv2d_nchw(n.fe[10], o3, nullptr, cls, N, H2, W2, st));                              // classif1.0
+        LWS_FE(launch_conv2d_nchw(n.fe[11], cls, nullptr, f2, N, H2, W2, st));                              // classif1.2 -> f2
+        if (ev != nullptr) LWS_HIP(hipEventRecord(ev[2], st));
+    }
 #undef LWS_FE
     return LWS_OK;
 }
@@ -936,10 +940,15 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     // The rest of the feature extractor (f4 for stage 2, f2 for stage 3) is launched on the side stream right after
     // stage 1's Conv3D stack: it overlaps with stage 1's regression and with stage 2 instead of competing with the
     // MFMA-bound stage-1 kernels for the CUs.
+    // (conv5 -> f4 is one short kernel: it goes to the side stream at once, so stage 2 never waits for it.)
+    LWS_HIP(hipEventRecord(h->ev_feat[0], st));
+    LWS_HIP(hipStreamWaitEvent(h->side, h->ev_feat[0], 0));
+    rc = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, h->side, h->ev_feat, 1);
+    if (rc) return rc;
     auto launch_tail = [&]() -> int {
         LWS_HIP(hipEventRecord(h->ev_feat[0], st));
         LWS_HIP(hipStreamWaitEvent(h->side, h->ev_feat[0], 0));
-        return feature_tail(h, 2 * B, H, W, L, f8, f4, f2, h->side, h->ev_feat);
+        return feature_tail(h, 2 * B, H, W, L, f8, f4, f2, h->side, h->ev_feat, 2);
     };
     rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st, h->ev_feat, launch_tail);     // :115-156
     if (rc) return rc;
