@@ -64,6 +64,7 @@ def main():
                          "overlaps consecutive steps: higher pairs/s, but kernels then share CUs and their in-situ "
                          "durations -- hence roofline.frac -- grow)")
     ap.add_argument("--size", default="256x512", help="HxW of the synthetic pairs (default: BASELINE config 2)")
+    ap.add_argument("--feature-fp16", action="store_true", help="BASELINE config 5: fp16-rounded feature maps")
     ap.add_argument("--maxdisp0", type=int, default=24, help="stage-1 hypotheses (24 = maxdisp 192, 32 = maxdisp 256)")
     args = ap.parse_args()
 
@@ -83,7 +84,7 @@ def main():
     torch.cuda.set_device(dev)
     import torch.distributed as dist
 
-    margs = default_args(maxdisplist=(args.maxdisp0, 5, 5))
+    margs = default_args(maxdisplist=(args.maxdisp0, 5, 5), feature_fp16=args.feature_fp16)
     sd = make_state_dict(7, margs)
     S = max(1, args.streams)
     models = [LWSNet(margs, device=dev).set_state_dict(sd).eval() for _ in range(S)]
@@ -224,7 +225,7 @@ def main():
         "metric": "stereo pairs/sec @256x512 maxdisp=192 (stage-4)",
         "value": round(pairs / elapsed, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp16-rounded features)" if args.feature_fp16 else "f32", "data": "synthetic",
         "config": {"workload": (f"BASELINE config 2: batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[24,5,5], all 4 stages"
                                 if (H, W, args.maxdisp0) == (256, 512, 24) else
                                 f"batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[{args.maxdisp0},5,5], all 4 stages"),

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LWS_ABI_VERSION 1
+#define LWS_ABI_VERSION 2
 
 typedef enum {
     LWS_OK = 0,
@@ -38,6 +38,10 @@ typedef struct {
     int32_t layers_3d;        /* 4 */
     int32_t channels_3d;      /* 8 */
     int32_t growth_rate[3];   /* {4,1,1}: c3 of stage i = channels_3d * growth_rate[i] */
+    int32_t feature_fp16;     /* 0 (reference behaviour).  1 = BASELINE config 5: the three feature maps are rounded to
+                                 fp16 (round-to-nearest-even) where the volume kernels read them; everything else,
+                                 including the soft-argmin, stays float32.  Not part of the reference; cannot meet the
+                                 1e-3 px tolerance, judged on 3-px error. */
 } lws_config;
 
 typedef struct lws_ctx *lws_handle;

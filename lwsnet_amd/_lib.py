@@ -18,7 +18,8 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 
 class LwsConfig(ctypes.Structure):
     _fields_ = [("maxdisplist", ctypes.c_int32 * 3), ("layers_3d", ctypes.c_int32),
-                ("channels_3d", ctypes.c_int32), ("growth_rate", ctypes.c_int32 * 3)]
+                ("channels_3d", ctypes.c_int32), ("growth_rate", ctypes.c_int32 * 3),
+                ("feature_fp16", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); exactly the functions include/lwsnet_hip.h declares
@@ -69,7 +70,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lws_abi_version() != 1:
+    if lib.lws_abi_version() != 2:
         raise RuntimeError("liblwsnet_hip.so ABI version mismatch; rebuild the extension")
     _lib = lib
     return lib

@@ -566,11 +566,11 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         if (s > 0 && feat_ready != nullptr) LWS_HIP(hipStreamWaitEvent(st, feat_ready[s], 0));
         if (s == 0) {
             ProfScope p(h, LWS_KC_VOLUME_SHIFT, st);
-            rc = launch_volume_l1_shift(featsL[0], featsR[0], raw, B, feat_c[0], hh, ww, D, st);            // :131
+            rc = launch_volume_l1_shift(featsL[0], featsR[0], raw, B, feat_c[0], hh, ww, D, st, h->cfg.feature_fp16 != 0);   // :131
         } else {
             ProfScope p(h, LWS_KC_VOLUME_WARP, st);
             rc = launch_volume_l1_warp(featsL[s], featsR[s], pred_out[s - 1], raw, nullptr, B, feat_c[s], hh, ww, H, W,
-                                       h->cfg.maxdisplist[s], st);                                           // :119-127
+                                       h->cfg.maxdisplist[s], st, h->cfg.feature_fp16 != 0);                  // :119-127
         }
         if (rc) return rc;
         const float start = s == 0 ? 0.0f : (float)(-h->cfg.maxdisplist[s] + 1);
@@ -627,6 +627,7 @@ int lws_create(const lws_config *cfg, lws_handle *out)
         LWS_CHECK_ARG(c3 == 8 || c3 == 16 || c3 == 32,
                       "stage %d: channels_3d*growth_rate = %d is not supported by the gfx950 kernels (8, 16, 32)", i, c3);
     }
+    LWS_CHECK_ARG(cfg->feature_fp16 == 0 || cfg->feature_fp16 == 1, "feature_fp16 must be 0 or 1 (got %d)", cfg->feature_fp16);
     lws_ctx *h = new (std::nothrow) lws_ctx();
     if (!h) {
         set_error("out of host memory");

@@ -138,10 +138,11 @@ struct lws_ctx {
 namespace lws {
 
 // ---- kernel launchers (lws_volume.hip, lws_regress.hip, lws_conv3d.hip) ----
+// q16: round the feature values to fp16 where they are read (lws_config.feature_fp16)
 int launch_volume_l1_shift(const float *L, const float *R, float *cost, int B, int C, int h, int w, int D,
-                           hipStream_t st);
+                           hipStream_t st, bool q16 = false);
 int launch_volume_l1_warp(const float *L, const float *R, const float *prev, float *cost, float *wflow_out,
-                          int B, int C, int h, int w, int H, int W, int m, hipStream_t st);
+                          int B, int C, int h, int w, int H, int W, int m, hipStream_t st, bool q16 = false);
 int launch_softargmin(const float *cost, float *low, int B, int D, int h, int w, float start, hipStream_t st);
 int launch_upsample_add(const float *low, const float *prev, float *out, int B, int h, int w, int H, int W,
                         hipStream_t st);

@@ -3,9 +3,18 @@
 //
 //   k_volume_l1_shift  <- LWSNet._build_volume_2d   /root/reference/models/models.py:58-76
 //   k_volume_l1_warp   <- forward() glue :119-121 + _build_volume_2d3 :78-104 + warp :28-55
+#include <hip/hip_fp16.h>
+
 #include "lws_common.h"
 
 namespace lws {
+
+// BASELINE config 5: feature values pass through fp16 (round-to-nearest-even) where the volume kernels read them.
+template <bool QH>
+__device__ __forceinline__ float qf(float x)
+{
+    return QH ? __half2float(__float2half_rn(x)) : x;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Stage-1 volume.  One workgroup = one image row segment of 64 pixels; the right-feature row
@@ -14,7 +23,7 @@ namespace lws {
 // pixel live in registers, and the 4 waves split the D hypotheses.  Global reads and writes
 // are coalesced along W.
 // ---------------------------------------------------------------------------------------------
-template <int C>
+template <int C, bool QH>
 __global__ __launch_bounds__(256) void k_volume_l1_shift(const float *__restrict__ L,
                                                          const float *__restrict__ R,
                                                          float *__restrict__ cost, int h, int w, int D)
@@ -39,8 +48,8 @@ __global__ __launch_bounds__(256) void k_volume_l1_shift(const float *__restrict
         }
 #pragma unroll
         for (int j = 0; j < C / 4; ++j) {
-            sR[(ty + 4 * j) * span + tx] = oka ? va[j] : 0.0f;
-            if (tx + 64 < span) sR[(ty + 4 * j) * span + tx + 64] = okb ? vb[j] : 0.0f;
+            sR[(ty + 4 * j) * span + tx] = oka ? qf<QH>(va[j]) : 0.0f;
+            if (tx + 64 < span) sR[(ty + 4 * j) * span + tx + 64] = okb ? qf<QH>(vb[j]) : 0.0f;
         }
     }
     __syncthreads();
@@ -49,7 +58,7 @@ __global__ __launch_bounds__(256) void k_volume_l1_shift(const float *__restrict
     float l[C];
     const float *Lb = L + (int64_t)b * C * plane + (int64_t)y * w + x;
 #pragma unroll
-    for (int c = 0; c < C; ++c) l[c] = Lb[(int64_t)c * plane];
+    for (int c = 0; c < C; ++c) l[c] = qf<QH>(Lb[(int64_t)c * plane]);
     float *out = cost + (int64_t)b * D * plane + (int64_t)y * w + x;
     for (int d = ty; d < D; d += 4) {
         const float *r = sR + tx + (D - 1) - d;
@@ -61,16 +70,20 @@ __global__ __launch_bounds__(256) void k_volume_l1_shift(const float *__restrict
 }
 
 int launch_volume_l1_shift(const float *L, const float *R, float *cost, int B, int C, int h, int w, int D,
-                           hipStream_t st)
+                           hipStream_t st, bool q16)
 {
     dim3 grid(cdiv(w, 64), h, B), block(64, 4);
     size_t lds = (size_t)C * (64 + D - 1) * sizeof(float);
+#define LWS_VS(CC)                                                                                            \
+    if (q16) hipLaunchKernelGGL((k_volume_l1_shift<CC, true>), grid, block, lds, st, L, R, cost, h, w, D);     \
+    else hipLaunchKernelGGL((k_volume_l1_shift<CC, false>), grid, block, lds, st, L, R, cost, h, w, D)
     switch (C) {
-        case 8: hipLaunchKernelGGL(k_volume_l1_shift<8>, grid, block, lds, st, L, R, cost, h, w, D); break;
-        case 16: hipLaunchKernelGGL(k_volume_l1_shift<16>, grid, block, lds, st, L, R, cost, h, w, D); break;
-        case 32: hipLaunchKernelGGL(k_volume_l1_shift<32>, grid, block, lds, st, L, R, cost, h, w, D); break;
+        case 8: LWS_VS(8); break;
+        case 16: LWS_VS(16); break;
+        case 32: LWS_VS(32); break;
         default: set_error("volume_l1_shift: unsupported channel count %d (8, 16, 32)", C); return LWS_ERR_INVALID;
     }
+#undef LWS_VS
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -99,7 +112,7 @@ __device__ __forceinline__ void src_index(int dst, float ratio, int in, int &i0,
 // The south taps are only touched when iy is not an exact integer (a wave-uniform branch,
 // exact because x + 0*v == x for finite v).
 // ---------------------------------------------------------------------------------------------
-template <int C>
+template <int C, bool QH>
 __global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict__ L,
                                                         const float *__restrict__ R,
                                                         const float *__restrict__ prev,
@@ -165,8 +178,8 @@ __global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict_
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float *rp = Rp + (int64_t)c * plane;
-            const float r_nw = rp[o_nw], r_ne = rp[o_ne];
-            const float l = Lp[(int64_t)c * plane];
+            const float r_nw = qf<QH>(rp[o_nw]), r_ne = qf<QH>(rp[o_ne]);
+            const float l = qf<QH>(Lp[(int64_t)c * plane]);
             float s = 0.0f;
             if (b_nw) s = s + r_nw * w_nw;
             if (b_ne) s = s + r_ne * w_ne;
@@ -176,8 +189,8 @@ __global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict_
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float *rp = Rp + (int64_t)c * plane;
-            const float r_nw = rp[o_nw], r_ne = rp[o_ne], r_sw = rp[o_sw], r_se = rp[o_se];
-            const float l = Lp[(int64_t)c * plane];
+            const float r_nw = qf<QH>(rp[o_nw]), r_ne = qf<QH>(rp[o_ne]), r_sw = qf<QH>(rp[o_sw]), r_se = qf<QH>(rp[o_se]);
+            const float l = qf<QH>(Lp[(int64_t)c * plane]);
             float s = 0.0f;
             if (b_nw) s = s + r_nw * w_nw;
             if (b_ne) s = s + r_ne * w_ne;
@@ -190,21 +203,23 @@ __global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict_
 }
 
 int launch_volume_l1_warp(const float *L, const float *R, const float *prev, float *cost, float *wflow_out,
-                          int B, int C, int h, int w, int H, int W, int m, hipStream_t st)
+                          int B, int C, int h, int w, int H, int W, int m, hipStream_t st, bool q16)
 {
     dim3 grid(cdiv(h * w, 256), 2 * m - 1, B), block(256);
     const float mul_a = (float)h, mul_b = 1.0f / (float)H;
+#define LWS_VW(CC)                                                                                                   \
+    if (q16)                                                                                                          \
+        hipLaunchKernelGGL((k_volume_l1_warp<CC, true>), grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m,  \
+                           mul_a, mul_b);                                                                             \
+    else                                                                                                              \
+        hipLaunchKernelGGL((k_volume_l1_warp<CC, false>), grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m, \
+                           mul_a, mul_b)
     switch (C) {
-        case 8:
-            hipLaunchKernelGGL(k_volume_l1_warp<8>, grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m,
-                               mul_a, mul_b);
-            break;
-        case 16:
-            hipLaunchKernelGGL(k_volume_l1_warp<16>, grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m,
-                               mul_a, mul_b);
-            break;
+        case 8: LWS_VW(8); break;
+        case 16: LWS_VW(16); break;
         default: set_error("volume_l1_warp: unsupported channel count %d (8, 16)", C); return LWS_ERR_INVALID;
     }
+#undef LWS_VW
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }

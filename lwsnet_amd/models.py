@@ -35,8 +35,9 @@ class LWSNet:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()) \
             if torch.cuda.is_available() else None
         lib = _lib.load()                                         # raises if the HIP extension is missing
+        self.feature_fp16 = bool(getattr(args, "feature_fp16", False))     # BASELINE config 5 (not in the reference)
         cfg = _lib.LwsConfig((ctypes.c_int32 * 3)(*self.maxdisplist), self.layers_3d, self.channels_3d,
-                             (ctypes.c_int32 * 3)(*self.growth_rate))
+                             (ctypes.c_int32 * 3)(*self.growth_rate), 1 if self.feature_fp16 else 0)
         self._h = ctypes.c_void_p()
         with self._device_ctx():
             _lib.check(lib.lws_create(ctypes.byref(cfg), ctypes.byref(self._h)), "lws_create")

@@ -48,6 +48,13 @@ def expf(x):
     return y
 
 
+def round_fp16(x):
+    x = _c(x)
+    y = np.empty_like(x)
+    lib().lwso_round_fp16(_p(x), _p(y), ctypes.c_int64(x.size))
+    return y
+
+
 def volume_l1_shift(L, R, D):
     L, R = _c(L), _c(R)
     B, C, h, w = L.shape
@@ -123,11 +130,14 @@ def conv3d_stack(cost, sd, stage):
     return y[:, 0]
 
 
-def disparity_stages(feats_l, feats_r, H, W, sd, maxdisplist=(24, 5, 5), return_costs=False):
-    """The three volume stages; returns [pred1, pred2, pred3] as [B,1,H,W] float32."""
+def disparity_stages(feats_l, feats_r, H, W, sd, maxdisplist=(24, 5, 5), return_costs=False, feature_fp16=False):
+    """The three volume stages; returns [pred1, pred2, pred3] as [B,1,H,W] float32.
+    feature_fp16 (BASELINE config 5): the feature maps are rounded to fp16 before the volumes are built."""
     pred, costs = [], []
     for s in range(3):
         fl, fr = _c(feats_l[s]), _c(feats_r[s])
+        if feature_fp16:
+            fl, fr = round_fp16(fl), round_fp16(fr)
         h, w = fl.shape[2:]
         if s == 0:
             raw = volume_l1_shift(fl, fr, maxdisplist[0])
@@ -233,13 +243,13 @@ def refine(left, pred3, sd):
     return bn_add_relu(v, None, pred3, False)        # pred[2] + disp_up (same-size resize is the identity)
 
 
-def forward(left, right, sd, maxdisplist=(24, 5, 5)):
+def forward(left, right, sd, maxdisplist=(24, 5, 5), feature_fp16=False):
     """LWSNet.forward (models.py:106-164) entirely through the C restatement."""
     left, right = _c(left), _c(right)
     B, _, H, W = left.shape
     both = feature_extraction(np.concatenate([left, right]), sd)
     fl = [f[:B] for f in both]
     fr = [f[B:] for f in both]
-    pred = disparity_stages(fl, fr, H, W, sd, maxdisplist)
+    pred = disparity_stages(fl, fr, H, W, sd, maxdisplist, feature_fp16=feature_fp16)
     pred.append(refine(left, pred[2], sd))
     return pred

@@ -19,6 +19,7 @@
  *   lwso_softargmin        models.py:142,151-152,167-179
  *   lwso_upsample_add      models.py:145-148,153-156
  */
+#include <immintrin.h>
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
@@ -45,6 +46,12 @@ static inline float lwso_expf(float x)
     u.f = y;
     u.i += ((int32_t)n) << 23;
     return u.f;
+}
+
+/* BASELINE config 5 (not in the reference): round every value to fp16 (round-to-nearest-even) and back. */
+LWSO_API void lwso_round_fp16(const float *x, float *y, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) y[i] = _cvtsh_ss(_cvtss_sh(x[i], _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
 }
 
 LWSO_API void lwso_expf_array(const float *x, float *y, int64_t n)

@@ -26,13 +26,13 @@ def test_header_and_prototypes_agree():
 def test_library_exports_every_symbol(hip_lib):
     for name in _declared():
         assert hasattr(hip_lib, name), name
-    assert hip_lib.lws_abi_version() == 1
+    assert hip_lib.lws_abi_version() == 2
 
 
 def _create(lib, **kw):
     a = default_args(**kw)
     cfg = _lib.LwsConfig((ctypes.c_int32 * 3)(*a.maxdisplist), a.layers_3d, a.channels_3d,
-                         (ctypes.c_int32 * 3)(*a.growth_rate))
+                         (ctypes.c_int32 * 3)(*a.growth_rate), 0)
     h = ctypes.c_void_p()
     rc = lib.lws_create(ctypes.byref(cfg), ctypes.byref(h))
     return rc, h
