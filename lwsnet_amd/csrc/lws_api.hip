@@ -321,13 +321,14 @@ static void build_net2d(const lws_ctx *h, std::vector<float> &slab, Net2dOffsets
         const bool seq = !d.tr && d.bn;   // convbn inside Sequential: <name>.0.weight / <name>.1.*
         const std::string wkey = d.tr ? fe + d.name + ".0.weight" : (d.bn ? fe + d.name + ".0.weight" : fe + d.name + ".weight");
         (void)seq;
-        {   // Conv2D [cout][cin][3][3] / Conv2DTranspose [cin][cout][3][3]  ->  [tap][cin][cout]
+        {   // Conv2D [cout][cin][3][3] / Conv2DTranspose [cin][cout][3][3]  ->  [tap][wave][cin][cout/4]
             const std::vector<float> &w = h->host.at(wkey);
+            const int cpt = d.cout / 4;
             std::vector<float> wt((size_t)9 * d.cin * d.cout);
             for (int co = 0; co < d.cout; ++co)
                 for (int ci = 0; ci < d.cin; ++ci)
                     for (int tap = 0; tap < 9; ++tap)
-                        wt[((size_t)tap * d.cin + ci) * d.cout + co] =
+                        wt[(((size_t)tap * 4 + co / cpt) * d.cin + ci) * cpt + co % cpt] =
                             d.tr ? w[((size_t)ci * d.cout + co) * 9 + tap] : w[((size_t)co * d.cin + ci) * 9 + tap];
             o.fe[i].w = sb.put(wt);
         }

@@ -32,7 +32,7 @@ __device__ __forceinline__ float f4c(const float4 &v, int j) { return j == 0 ? v
 // Workgroup = an 8 x 8 output tile of one image, ALL output channels: the input region the tile needs (all CIN
 // planes, zero outside the image) is staged once in LDS with every global load in flight; wave w then computes
 // output channels [w*COUT/4, (w+1)*COUT/4) for the 64 pixels (one pixel per lane), so the weights
-// ([tap][cin][cout]) are wave-uniform and come through the scalar cache.
+// ([tap][wave][cin][COUT/4]) are wave-uniform and come through the scalar cache.
 // Epilogue: BatchNorm (optional) -> + residual (optional) -> ReLU (optional).
 // =============================================================================================
 template <int CIN, int COUT, bool TRANSPOSED>
@@ -49,12 +49,14 @@ __global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ i
     extern __shared__ float sIn[];   // [CIN][RH][RWp]
     const int b = blockIdx.z;
     const int tid = threadIdx.x, tx = tid & 7, ty = (tid >> 3) & 7;
-    const int co0 = (tid >> 6) * CPT;                       // wave-uniform
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: the weight addresses below become scalar loads
+    const int co0 = wave_id * CPT;
     const int ox0 = blockIdx.x * 8, oy0 = blockIdx.y * 8;
     const int ry0 = TRANSPOSED ? ((oy0 - 1) >> 1) : oy0 * stride - pad;
     const int rx0 = TRANSPOSED ? ((ox0 - 1) >> 1) : ox0 * stride - pad;
     const int plane = H * W, oplane = Ho * Wo;
     const float *inb = b < n1 ? in + (int64_t)b * CIN * plane : in2 + (int64_t)(b - n1) * CIN * plane;
+    LWS_STAMP(0);
     // region positions are decoded once per thread (<= 2 positions: RH*RW <= 19*19), then all CIN planes of a
     // position are loaded back to back (unconditional clamped loads, masked afterwards)
     const int rsz = RH * RW;
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ i
         }
     }
     __syncthreads();
+    LWS_STAMP(1);
     const int ox = ox0 + tx, oy = oy0 + ty;
     if (ox >= Wo || oy >= Ho) return;
     float acc[CPT];
@@ -96,15 +99,18 @@ __global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ i
             lx = tx * stride + kw * dil;
         }
         const float *p = sIn + (ok ? ly * RWp + lx : 0);
-        const float *w = wgt + tap * CIN * COUT + co0;
+        // weights are packed [tap][wave][cin][CPT]: the CIN*CPT values a wave needs for one tap are contiguous, so they
+        // arrive in a few wide scalar loads (one 8-byte s_load per (tap, cin) made this loop latency-bound)
+        const float *w = wgt + (tap * 4 + wave_id) * CIN * CPT;
         float v[CIN];
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci) v[ci] = ok ? p[ci * cstride] : 0.0f;
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-            for (int c = 0; c < CPT; ++c) acc[c] = fmaf(v[ci], w[ci * COUT + c], acc[c]);
+            for (int c = 0; c < CPT; ++c) acc[c] = fmaf(v[ci], w[ci * CPT + c], acc[c]);
     }
+    LWS_STAMP(2);
     const int64_t o = ((int64_t)b * COUT + co0) * oplane + oy * Wo + ox;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ i
         if (relu) v = fmaxf(v, 0.0f);
         out[o + (int64_t)c * oplane] = v;
     }
+    LWS_STAMP(3);
 }
 
 template <int CIN, int COUT, bool TR>
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256) void k_conv2d_pair(const float *__restrict__ i
     float *sIn = smem;                       // [CIN][RH][RWp]
     float *sMid = smem + CIN * RH * RWp;     // [CM][MR][MRp]
     const int b = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ox0 = blockIdx.x * 8, oy0 = blockIdx.y * 8;
     const int my0 = oy0 - dilB, mx0 = ox0 - dilB;                 // origin of the intermediate region (A-output coords)
     const int iy0 = my0 * strideA - padA, ix0 = mx0 * strideA - padA;
@@ -214,14 +221,14 @@ __global__ __launch_bounds__(256) void k_conv2d_pair(const float *__restrict__ i
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap - kh * 3;
                 const float *pp = sIn + (my * strideA + kh * dilA) * RWp + mx * strideA + kw * dilA;
-                const float *w = wA + tap * CIN * CM + coA;
+                const float *w = wA + (tap * 4 + wave) * CIN * CPA;
                 float v[CIN];
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) v[ci] = pp[ci * RH * RWp];
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-                    for (int c = 0; c < CPA; ++c) acc[c] = fmaf(v[ci], w[ci * CM + c], acc[c]);
+                    for (int c = 0; c < CPA; ++c) acc[c] = fmaf(v[ci], w[ci * CPA + c], acc[c]);
             }
 #pragma unroll
             for (int c = 0; c < CPA; ++c) {
@@ -244,14 +251,14 @@ __global__ __launch_bounds__(256) void k_conv2d_pair(const float *__restrict__ i
     for (int tap = 0; tap < 9; ++tap) {
         const int kh = tap / 3, kw = tap - kh * 3;
         const float *pp = sMid + (ty + kh * dilB) * MRp + tx + kw * dilB;
-        const float *w = wB + tap * CM * COUT + coB;
+        const float *w = wB + (tap * 4 + wave) * CM * CPB;
         float v[CM];
 #pragma unroll
         for (int ci = 0; ci < CM; ++ci) v[ci] = pp[ci * MR * MRp];
 #pragma unroll
         for (int ci = 0; ci < CM; ++ci)
 #pragma unroll
-            for (int c = 0; c < CPB; ++c) acc[c] = fmaf(v[ci], w[ci * COUT + c], acc[c]);
+            for (int c = 0; c < CPB; ++c) acc[c] = fmaf(v[ci], w[ci * CPB + c], acc[c]);
     }
     const int oplane = HA * WA;
     const int64_t o = ((int64_t)b * COUT + coB) * oplane + oy * WA + ox;

@@ -13,7 +13,13 @@ m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
 lib = ctypes.CDLL(_lib.LIB_PATH)
 what = sys.argv[1] if len(sys.argv) > 1 else "0"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-if what in ("dws", "conv64"):   # last k_ref_dws launch of the refinement (dilation 1) / the k_ref_conv64 launch
+if what == "feat":      # last k_conv2d_nchw launch of the feature extractor (classif1.2, 8 -> 8 at 1/2 resolution)
+    TU = "conv2d"
+    img = torch.randn((2 * B, 3, 256, 512), device=dev)
+    for _ in range(3):
+        ops.feature_extraction(m._h, img)
+    stage = -1
+elif what in ("dws", "conv64"):   # last k_ref_dws launch of the refinement (dilation 1) / the k_ref_conv64 launch
     TU = "conv2d"
     left = torch.randn((B, 3, 256, 512), device=dev)
     p3 = torch.rand((B, 1, 256, 512), device=dev) * 100
