@@ -420,13 +420,13 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
     }                                                  \
     if (rc) return rc;
     // layers up to the 1/8 map (dres0, dres1, hourglass conv1..conv4) for `cnt` images starting at batch index i0 on
-    // stream s; images [0, n1) are read from img, the rest from img2.  LWS_PAIR=1 runs consecutive layers pairwise in
-    // one launch (k_conv2d_pair, bit-identical).  Measured r01 on MI355X: 22.4 us per pair vs 2 x 14.4 us per layer in
-    // isolation, but 1429 vs 1474 pairs/s end to end at B = 1 (and worse at B = 8): the halo recompute of the first
-    // layer costs more than the saved launch, so one kernel per layer stays the default.
+    // stream s; images [0, n1) are read from img, the rest from img2.  Consecutive layers run pairwise in one launch
+    // (k_conv2d_pair, bit-identical to one kernel per layer); LWS_PAIR=0 selects one kernel per layer.  Measured r01 on
+    // MI355X after the scalar-weight fix: 1,704 vs 1,688 pairs/s at B = 1, 2,750 vs 2,730 at B = 8, 749 vs 753 at
+    // B = 8 368x1232 -- four launches fewer on the critical path against the halo recompute of the first layer.
     static const bool no_pair = [] {
         const char *e = getenv("LWS_PAIR");
-        return !(e != nullptr && atoi(e) != 0);
+        return e != nullptr && atoi(e) == 0;
     }();
     auto head = [&](hipStream_t s, const float *img, const float *img2, int n1, int i0, int cnt) -> int {
         hipStream_t st = s;   // (the profiling macro names the stream `st`)
