@@ -35,8 +35,10 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// Diagnostic builds only (LWS_EXTRA_FLAGS=-DLWS_STAMPS; tools/stamps.py): every workgroup stores s_memtime stamps of
-// its phases in a per-translation-unit buffer; the shipped library compiles LWS_STAMP to nothing.
+// Diagnostic builds only (LWS_EXTRA_FLAGS="-DLWS_STAMPS=<kernel id>"; tools/stamps.py): every workgroup of the selected
+// kernel stores s_memtime stamps of its phases in a per-translation-unit buffer.  The shipped library compiles
+// LWS_STAMPK to nothing.  Kernel ids: 1 mid16, 2 mid8, 3 conv3d_last, 4 conv3d_first, 5 ref_dws, 6 ref_conv64,
+// 7 conv2d_nchw, 8 ref_first, 9 ref_last, 10 volume_warp, 11 volume_shift, 12 softargmin_upsample, 13 conv2d_pair.
 #ifdef LWS_STAMPS
 #define LWS_DEFINE_STAMPS(tu)                                                                                      \
     __device__ unsigned long long g_stamps_##tu[4096 * 8];                                                         \
@@ -53,10 +55,13 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
     {                                                                                                              \
         return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_##tu), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1; \
     }
-#define LWS_STAMP(i) stamp_(i)
+#define LWS_STAMPK(k, i)                 \
+    do {                                 \
+        if ((k) == LWS_STAMPS) stamp_(i); \
+    } while (0)
 #else
 #define LWS_DEFINE_STAMPS(tu)
-#define LWS_STAMP(i) do {} while (0)
+#define LWS_STAMPK(k, i) do {} while (0)
 #endif
 
 // One BatchNorm3D -> ReLU -> Conv3D layer, device side.

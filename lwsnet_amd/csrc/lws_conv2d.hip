@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ i
     const int rx0 = TRANSPOSED ? ((ox0 - 1) >> 1) : ox0 * stride - pad;
     const int plane = H * W, oplane = Ho * Wo;
     const float *inb = b < n1 ? in + (int64_t)b * CIN * plane : in2 + (int64_t)(b - n1) * CIN * plane;
-    LWS_STAMP(0);
+    LWS_STAMPK(7, 0);
     // region positions are decoded once per thread (<= 2 positions: RH*RW <= 19*19), then all CIN planes of a
     // position are loaded back to back (unconditional clamped loads, masked afterwards)
     const int rsz = RH * RW;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ i
         }
     }
     __syncthreads();
-    LWS_STAMP(1);
+    LWS_STAMPK(7, 1);
     const int ox = ox0 + tx, oy = oy0 + ty;
     if (ox >= Wo || oy >= Ho) return;
     float acc[CPT];
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ i
 #pragma unroll
             for (int c = 0; c < CPT; ++c) acc[c] = fmaf(v[ci], w[ci * CPT + c], acc[c]);
     }
-    LWS_STAMP(2);
+    LWS_STAMPK(7, 2);
     const int64_t o = ((int64_t)b * COUT + co0) * oplane + oy * Wo + ox;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_conv2d_nchw(const float *__restrict__ i
         if (relu) v = fmaxf(v, 0.0f);
         out[o + (int64_t)c * oplane] = v;
     }
-    LWS_STAMP(3);
+    LWS_STAMPK(7, 3);
 }
 
 template <int CIN, int COUT, bool TR>
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RefTile t = ref_tile(dil, nbx, nby);
     const float *inb = in + (int64_t)t.b * H * W * 32;
-    LWS_STAMP(0);
+    LWS_STAMPK(5, 0);
 
     const int c4 = tid & 7;
     const float4 s4 = *reinterpret_cast<const float4 *>(bn_s + c4 * 4);
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
         if (hp < NPX) sA[c4 * DWS_SA + hp] = v;
     }
     __syncthreads();
-    LWS_STAMP(1);
+    LWS_STAMPK(5, 1);
 
     // 2. depthwise: tile pixel p = (tid >> 3) + 32 i  ->  row (tid >> 7) + 2 i, column (tid >> 3) & 15
     {
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
         }
     }
     __syncthreads();
-    LWS_STAMP(2);
+    LWS_STAMPK(5, 2);
 
     // 3. pointwise MFMA: wave handles tile rows 2*wave, 2*wave+1 x both output-channel tiles
     const int n = lane & 15, g = lane >> 4;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
                 for (int mt = 0; mt < 2; ++mt)
                     acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(aw[q][mt], j), f4c(bv[r][q], j), acc[r][mt], 0, 0, 0);
 
-    LWS_STAMP(3);
+    LWS_STAMPK(5, 3);
     // 4. store: lane (n, g) holds channels 16mt + 4g .. +3 of pixel (row, n)
     float *outb = out + (int64_t)t.b * H * W * 32;
     const int gx = t.X0 + n * dil;
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RefTile t = ref_tile(dil, nbx, nby, TY);
     const int n = lane & 15, g = lane >> 4;
-    LWS_STAMP(4);
+    LWS_STAMPK(6, 0);
 
     // stage: item = (tensor, halo pixel, 16-channel group) = 64 bytes
     constexpr int ITEMS = 2 * NPX * 2, SITER = (ITEMS + 255) / 256;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) wbuf[0][qq][mt] = wp[(qq * 2 + mt) * 64];
     __syncthreads();
-    LWS_STAMP(5);
+    LWS_STAMPK(6, 1);
 
     floatx4 acc[RW][2];
 #pragma unroll
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) wbuf[0][qq][mt] = wbuf[1][qq][mt];
     }
-    LWS_STAMP(6);
+    LWS_STAMPK(6, 2);
     float *outb = out + (int64_t)t.b * H * W * 32;
     const int gx = t.X0 + n * dil;
 #pragma unroll
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
                     make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
         }
     }
-    LWS_STAMP(7);
+    LWS_STAMPK(6, 3);
 }
 
 // =============================================================================================
@@ -672,6 +672,7 @@ __global__ __launch_bounds__(256) void k_ref_last(const float *__restrict__ in, 
     const int tid = threadIdx.x, b = blockIdx.z;
     const int x0 = blockIdx.x * LAST_TX, y0 = blockIdx.y * LAST_TY;
     const float *inb = in + (int64_t)b * H * W * 32;
+    LWS_STAMPK(9, 0);
     constexpr int ITEMS = LAST_NPX * 8, SITER = (ITEMS + 255) / 256;
     const int c4 = tid & 7;
     float4 c[SITER];
@@ -690,8 +691,12 @@ __global__ __launch_bounds__(256) void k_ref_last(const float *__restrict__ in, 
         if (hp < LAST_NPX) sA[c4 * LAST_PS + hp] = okv[i] ? c[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    LWS_STAMPK(9, 1);
     const int tx = tid & 31, ty = tid >> 5;
     const int x = x0 + tx, y = y0 + ty;
+    const bool live = x < W && y < H;
+    const int64_t o = ((int64_t)b * H + (live ? y : 0)) * W + (live ? x : 0);
+    const float skip = pred3[o];                      // issued now: its latency hides behind the 288 fmas
     float acc = 0.0f;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
@@ -708,10 +713,9 @@ __global__ __launch_bounds__(256) void k_ref_last(const float *__restrict__ in, 
                 acc = fmaf(a.w, w[g8 * 4 + 3], acc);
             }
         }
-    if (x < W && y < H) {
-        const int64_t o = ((int64_t)b * H + y) * W + x;
-        out[o] = acc + pred3[o];
-    }
+    LWS_STAMPK(9, 2);
+    if (live) out[o] = acc + skip;
+    LWS_STAMPK(9, 3);
 }
 
 // =============================================================================================

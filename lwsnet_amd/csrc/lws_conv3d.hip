@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
     const int b = blockIdx.y;
     const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * C3;
-    LWS_STAMP(0);
+    LWS_STAMPK(1, 0);
 
     // ---- stage the halo tile: one item = (voxel, 16-channel group) = 64 contiguous bytes.  All global loads
     //      of a thread are issued first (SITER x 4 float4 in flight), then transposed 4x4 and written to LDS.
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) wbuf[0][q][mt] = wp[(q * MT + mt) * 64];
     __syncthreads();
-    LWS_STAMP(1);
+    LWS_STAMPK(1, 1);
 
     floatx4 acc[RW][MTW];
 #pragma unroll
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
         }
     }
 
-    LWS_STAMP(2);
+    LWS_STAMPK(1, 2);
     // ---- epilogue: D[i][j]: row i = 4*(lane>>4) + reg = output channel in the tile, col j = lane&15 = voxel.
     //      Apply the NEXT layer's BatchNorm + ReLU and store 4 consecutive channels of one voxel (16 B).
     float *outb = out + (int64_t)b * D * h * w * C3;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
             }
         }
     }
-    LWS_STAMP(3);
+    LWS_STAMPK(1, 3);
 }
 
 // =============================================================================================
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
     const int b = blockIdx.y;
     const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * 8;
-    LWS_STAMP(0);
+    LWS_STAMPK(2, 0);
 
     // 72 A fragments of this lane as 18 float4 ([step/4][lane][4]): 18 wide loads instead of 72 dword loads
     float wa[72];
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
         }
     }
     __syncthreads();
-    LWS_STAMP(1);
+    LWS_STAMPK(2, 1);
 
     floatx4 acc[RW];
     int rbase[RW];
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
                     }
                 }
 
-    LWS_STAMP(2);
+    LWS_STAMPK(2, 2);
     // ---- epilogue: row i = 4*(lane>>4) + reg -> xpar = (lane>>4)>>1, cout = 4*((lane>>4)&1) + reg ----
     float *outb = out + (int64_t)b * D * h * w * 8;
     const int xpar = g >> 1, cb = 4 * (g & 1);
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
             *reinterpret_cast<float4 *>(outb + (((int64_t)gd * h + gy) * w + gx) * 8 + cb) = v;
         }
     }
-    LWS_STAMP(3);
+    LWS_STAMPK(2, 3);
 }
 
 // =============================================================================================

@@ -9,6 +9,8 @@
 
 namespace lws {
 
+LWS_DEFINE_STAMPS(volume)
+
 // BASELINE config 5: feature values pass through fp16 (round-to-nearest-even) where the volume kernels read them.
 template <bool QH>
 __device__ __forceinline__ float qf(float x)
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict_
     const int64_t plane = (int64_t)h * w;
     if (pix >= plane) return;
     const int y = pix / w, x = pix - y * w;
+    LWS_STAMPK(10, 0);
 
     // wflow = resize(prev)[y,x] * float(h) * float32(1/H)            (models.py:119-121)
     float wf;
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict_
         wf = wf * mul_b;
     }
     if (wflow_out != nullptr && k == 0) wflow_out[(int64_t)b * plane + pix] = wf;
+    LWS_STAMPK(10, 1);
 
     const float rw = 1.0f / (float)(w - 1 > 1 ? w - 1 : 1);
     const float rh = 1.0f / (float)(h - 1 > 1 ? h - 1 : 1);
@@ -199,7 +203,9 @@ __global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict_
             acc = acc + fabsf(l - s);                    // :101
         }
     }
+    LWS_STAMPK(10, 2);
     cost[((int64_t)b * (2 * m - 1) + k) * plane + pix] = acc;
+    LWS_STAMPK(10, 3);
 }
 
 int launch_volume_l1_warp(const float *L, const float *R, const float *prev, float *cost, float *wflow_out,

@@ -1,9 +1,23 @@
-"""Diagnostic: per-workgroup phase stamps of the Conv3D MFMA kernels (library built with LWS_EXTRA_FLAGS=-DLWS_STAMPS).
+"""Diagnostic: per-workgroup phase stamps (s_memtime, shader cycles) of one kernel.
 
-    LWS_EXTRA_FLAGS=-DLWS_STAMPS python -m lwsnet_amd.build --force && python tools/stamps.py [stage] [batch]
-Prints median shader cycles of: staging (0->1), MFMA loop (1->2), epilogue (2->3) of the LAST mid-layer launch."""
-import ctypes, sys
+    python tools/stamps.py <kernel> [batch]     # rebuilds the library with -DLWS_STAMPS=<id>, runs, prints medians
+kernels: mid16 mid8s2 mid8s3 last1 last3 first1 first3 dws conv64 feat ref_first ref_last warp2 warp3
+Slots: 0..3 = phase boundaries as placed in the kernel source (LWS_STAMPK)."""
+import ctypes, os, subprocess, sys
 sys.path.insert(0, '/root/repo')
+KERNELS = {  # name: (stamp id, translation unit, driver, arg)
+    "mid16": (1, "conv3d", "stack", 0), "mid8s2": (2, "conv3d", "stack", 1), "mid8s3": (2, "conv3d", "stack", 2),
+    "last1": (3, "conv3d", "stack", 0), "last3": (3, "conv3d", "stack", 2),
+    
+    "dws": (5, "conv2d", "refine", None), "conv64": (6, "conv2d", "refine", None),
+    "feat": (7, "conv2d", "feat", None), "ref_last": (9, "conv2d", "refine", None),
+    "warp2": (10, "volume", "stages", None), "warp3": (10, "volume", "stages", None),
+}
+what = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+kid, TU, driver, arg = KERNELS[what]
+env = dict(os.environ, LWS_EXTRA_FLAGS=f"-DLWS_STAMPS={kid}")
+subprocess.check_call([sys.executable, "-m", "lwsnet_amd.build", "--force"], env=env, stdout=subprocess.DEVNULL, cwd="/root/repo")
 import numpy as np, torch
 from lwsnet_amd import _lib, ops
 from lwsnet_amd.models import LWSNet
@@ -11,39 +25,34 @@ from lwsnet_amd.weights import default_args, make_state_dict
 dev = torch.device('cuda:0')
 m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
 lib = ctypes.CDLL(_lib.LIB_PATH)
-what = sys.argv[1] if len(sys.argv) > 1 else "0"
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-if what == "feat":      # last k_conv2d_nchw launch of the feature extractor (classif1.2, 8 -> 8 at 1/2 resolution)
-    TU = "conv2d"
-    img = torch.randn((2 * B, 3, 256, 512), device=dev)
-    for _ in range(3):
-        ops.feature_extraction(m._h, img)
-    stage = -1
-elif what in ("dws", "conv64"):   # last k_ref_dws launch of the refinement (dilation 1) / the k_ref_conv64 launch
-    TU = "conv2d"
+if driver == "stack":
+    shape = [(B, 24, 32, 64), (B, 9, 64, 128), (B, 9, 128, 256)][arg]
+    c = torch.rand(shape, device=dev) * 12
+    for _ in range(5):
+        ops.conv3d_stack(m._h, arg, c)
+elif driver == "refine":
     left = torch.randn((B, 3, 256, 512), device=dev)
     p3 = torch.rand((B, 1, 256, 512), device=dev) * 100
     for _ in range(3):
         ops.refine(m._h, left, p3)
-    stage = -1
-else:
-    TU = "conv3d"
-    stage = int(what)
-    shape = [(B, 24, 32, 64), (B, 9, 64, 128), (B, 9, 128, 256)][stage]
-    c = torch.rand(shape, device=dev) * 12
-    for _ in range(5):
-        ops.conv3d_stack(m._h, stage, c)
+elif driver == "feat":
+    img = torch.randn((2 * B, 3, 256, 512), device=dev)
+    for _ in range(3):
+        ops.feature_extraction(m._h, img)
+elif driver == "stages":
+    rng = np.random.default_rng(0)
+    shapes = [(B, 16, 32, 64), (B, 16, 64, 128), (B, 8, 128, 256)]
+    fl = [torch.from_numpy(np.abs(rng.standard_normal(s)).astype(np.float32)).to(dev) for s in shapes]
+    fr = [torch.from_numpy(np.abs(rng.standard_normal(s)).astype(np.float32)).to(dev) for s in shapes]
+    for _ in range(3):
+        ops.disparity_stages(m._h, fl, fr, 256, 512)
 torch.cuda.synchronize()
 n = 4096 * 8
 buf = (ctypes.c_ulonglong * n)()
 assert getattr(lib, "lws_debug_read_stamps_" + TU)(buf, n) == 0
-NS = 4
-raw = np.array(buf, dtype=np.int64).reshape(-1, 8)
-s = raw[:, 4:8] if what == "conv64" else raw[:, :NS]
-s = s[s[:, 0] > 0]
-print(f"{what} B={B}: workgroups with stamps: {len(s)}")
-phases = ((0, 1, "staging"), (1, 2, "depthwise"), (2, 3, "pointwise"), (0, 3, "total")) if what == "dws" else \
-    ((0, 1, "staging"), (1, 2, "mfma loop"), (2, 3, "epilogue"), (0, 3, "total"))
-for a, b, name in phases:
+s = np.array(buf, dtype=np.int64).reshape(-1, 8)[:, :4]
+s = s[(s[:, 0] > 0) & (s[:, 3] > 0)]
+print(f"{what} B={B}: workgroups with stamps: {len(s)} (last launch of this kernel)")
+for a, b in ((0, 1), (1, 2), (2, 3), (0, 3)):
     d = s[:, b] - s[:, a]
-    print(f"  {name:10s} median {np.median(d):8.0f}  p10 {np.percentile(d,10):8.0f}  p90 {np.percentile(d,90):8.0f} cycles")
+    print(f"  stamp {a}->{b}: median {np.median(d):8.0f}  p10 {np.percentile(d,10):8.0f}  p90 {np.percentile(d,90):8.0f} cycles")
