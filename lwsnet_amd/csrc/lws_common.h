@@ -35,6 +35,24 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// 16-byte activation store.  wt (wave-uniform) selects a write-through store (sc0 sc1): the line does not stay dirty in
+// the XCD's L2, so the end-of-kernel release has less to write back.  Measured r01 on MI355X in k_ref_dws: 12.5 -> 11.7 us
+// per launch at B = 1 (16.8 MB written) but 78.7 -> 95.8 us at B = 8 (134 MB), so launchers enable it for small outputs only.
+__device__ __forceinline__ void store_act4(float *p, float4 v, int wt)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (wt) {
+        typedef float fx4_ __attribute__((ext_vector_type(4)));
+        const fx4_ r = {v.x, v.y, v.z, v.w};
+        // (s_nop 1 inside the string: hipcc must not overwrite the data registers before the store has read them)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
+        return;
+    }
+#endif
+    *reinterpret_cast<float4 *>(p) = v;
+}
+static inline int use_wt_stores(size_t out_bytes) { return out_bytes <= ((size_t)40 << 20) ? 1 : 0; }
+
 // Diagnostic builds only (LWS_EXTRA_FLAGS="-DLWS_STAMPS=<kernel id>"; tools/stamps.py): every workgroup of the selected
 // kernel stores s_memtime stamps of its phases in a per-translation-unit buffer.  The shipped library compiles
 // LWS_STAMPK to nothing.  Kernel ids: 1 mid16, 2 mid8, 3 conv3d_last, 4 conv3d_first, 5 ref_dws, 6 ref_conv64,

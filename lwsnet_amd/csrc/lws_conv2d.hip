@@ -415,7 +415,7 @@ constexpr int DWS_SA = 186, DWS_SB = 130;
 __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, const float *__restrict__ bn_s,
                                                  const float *__restrict__ bn_t, const float *__restrict__ dw,   // [tap][32]
                                                  const float4 *__restrict__ pwpk,                              // [q][mt][lane]
-                                                 float *__restrict__ out, int H, int W, int dil, int nbx, int nby)
+                                                 float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt)
 {
     __shared__ float4 sA[8 * DWS_SA];
     __shared__ float4 sB[8 * DWS_SB];
@@ -523,8 +523,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
             float *o = outb + (gy * W + gx) * 32;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
-                *reinterpret_cast<float4 *>(o + mt * 16 + 4 * g) =
-                    make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
+                store_act4(o + mt * 16 + 4 * g, make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]), wt);
         }
     }
 }
@@ -539,7 +538,7 @@ template <int TY>   // tile rows (4 waves: TY/4 rows each)
 __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ inL, const float *__restrict__ inD,
                                                     const float *__restrict__ bn_s, const float *__restrict__ bn_t,   // [64]
                                                     const float4 *__restrict__ wpk,   // [tap][qq][mt][lane]
-                                                    float *__restrict__ out, int H, int W, int dil, int nbx, int nby)
+                                                    float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt)
 {
     constexpr int HY = TY + 2, NPX = HY * RH_X, RW = TY / 4;
     __shared__ __attribute__((aligned(16))) float sA[2 * NPX * RVS];
@@ -650,8 +649,7 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
             float *o = outb + ((int64_t)gy * W + gx) * 32;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
-                *reinterpret_cast<float4 *>(o + mt * 16 + 4 * g) =
-                    make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]);
+                store_act4(o + mt * 16 + 4 * g, make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]), wt);
         }
     }
     LWS_STAMPK(6, 3);
@@ -739,7 +737,7 @@ int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, i
     const int nbx = cdiv(W, RT_X * l.dil), nby = cdiv(H, RT_Y * l.dil);
     dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
     hipLaunchKernelGGL(k_ref_dws, grid, block, 0, st, in, l.bn_s, l.bn_t, l.dw, reinterpret_cast<const float4 *>(l.pw),
-                       out, H, W, l.dil, nbx, nby);
+                       out, H, W, l.dil, nbx, nby, use_wt_stores((size_t)B * H * W * 128));
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -759,14 +757,16 @@ int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, fl
         const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, TY * dil);
         dim3 grid(nbx * nby * dil * dil * B), block(256);
         hipLaunchKernelGGL(k_ref_conv64<TY>, grid, block, 0, st, inL, inD, l.bn_s, l.bn_t,
-                           reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby);
+                           reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby,
+                           use_wt_stores((size_t)B * H * W * 128));
     } else {
         // 4-row tiles: 27 KB of LDS per workgroup -> 5 workgroups (5 waves per SIMD) share each CU's MFMA pipes
         constexpr int TY = 4;
         const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, TY * dil);
         dim3 grid(nbx * nby * dil * dil * B), block(256);
         hipLaunchKernelGGL(k_ref_conv64<TY>, grid, block, 0, st, inL, inD, l.bn_s, l.bn_t,
-                           reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby);
+                           reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby,
+                           use_wt_stores((size_t)B * H * W * 128));
     }
     LWS_LAUNCH_CHECK();
     return LWS_OK;

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
                                                               const float *__restrict__ bn_s,   // next layer BN [C3]
                                                               const float *__restrict__ bn_t,
                                                               float *__restrict__ out, int D, int h, int w,
-                                                              int tiles_x, int tiles_y)
+                                                              int tiles_x, int tiles_y, int wt)
 {
     using Cfg = Mid16Cfg<C3, TD, TY, WR, WM>;
     constexpr int MT = Cfg::MT, Q = Cfg::Q, RW = Cfg::RW, MTW = Cfg::MTW, HY = Cfg::HY, HX = Cfg::HX, VS = Cfg::VS;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
                 v.y = bn_relu(acc[r][mt][1], s.y, t.y);
                 v.z = bn_relu(acc[r][mt][2], s.z, t.z);
                 v.w = bn_relu(acc[r][mt][3], s.w, t.w);
-                *reinterpret_cast<float4 *>(o + cb) = v;
+                store_act4(o + cb, v, wt);
             }
         }
     }
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
                                                      const float *__restrict__ bn_s,    // next layer BN [8]
                                                      const float *__restrict__ bn_t,
                                                      float *__restrict__ out, int D, int h, int w,
-                                                     int tiles_x, int tiles_y)
+                                                     int tiles_x, int tiles_y, int wt)
 {
     using Cfg = Mid8Cfg<TD, TY>;
     constexpr int RW = Cfg::RW, HY = Cfg::HY, HX = Cfg::HX, PS = Cfg::PS;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
             v.y = bn_relu(acc[r][1], s.y, t.y);
             v.z = bn_relu(acc[r][2], s.z, t.z);
             v.w = bn_relu(acc[r][3], s.w, t.w);
-            *reinterpret_cast<float4 *>(outb + (((int64_t)gd * h + gy) * w + gx) * 8 + cb) = v;
+            store_act4(outb + (((int64_t)gd * h + gy) * w + gx) * 8 + cb, v, wt);
         }
     }
     LWS_STAMPK(2, 3);
@@ -643,15 +643,18 @@ static int mid16_launch(const Stage3d &s, int layer, const float *in, float *out
     const int tiles_x = cdiv(w, 16), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
     block = dim3(Cfg::NT);
+    // write-through stores were measured a loss here (26.3 -> 27.6 us at B = 1): the next layer re-reads these
+    // activations at once and finds them in the XCD's L2 only when they were stored write-back
+    const int wt = 0;
     if (e0 != nullptr) {
         // profiler on: the events carry the kernel's own begin / end timestamps (no dispatch latency in between)
         hipExtLaunchKernelGGL((k_conv3d_mid16<C3, TD, TY, WR, WM>), grid, block, Cfg::LDS_BYTES, st, e0, e1, 0, in,
                               reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
-                              s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y);
+                              s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt);
     } else {
         hipLaunchKernelGGL((k_conv3d_mid16<C3, TD, TY, WR, WM>), grid, block, Cfg::LDS_BYTES, st, in,
                            reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
-                           s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y);
+                           s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt);
     }
     LWS_LAUNCH_CHECK();
     return LWS_OK;
@@ -671,7 +674,7 @@ static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out,
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
     hipLaunchKernelGGL((k_conv3d_mid8<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w,
-                       s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y);
+                       s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, /*wt=*/0);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
