@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    int tile = blockIdx.x;
+    int tile = xcd_tile(blockIdx.x, gridDim.x);   // same XCD-contiguous tile map in every layer of the stack
     const int tx = tile % tiles_x;
     tile /= tiles_x;
     const int ty = tile % tiles_y;
