@@ -527,8 +527,17 @@ static int refine_rest(lws_ctx *h, const float *pred3, int B, int H, int W, cons
     const Net2d &n = h->net2d;
     float *ra = h->ws + L.r_a, *rb = h->ws + L.r_b, *rc_ = h->ws + L.r_c;
     int rc;
-    LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(pred3, 1, n.r1_first[1], rb, B, H, W, st));
-    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][0], rb, rc_, B, H, W, st));
+    static const bool fuse_first = [] {
+        const char *e = getenv("LWS_FUSE_FIRST");
+        return e ? atoi(e) != 0 : true;
+    }();
+    if (fuse_first && ref_first_dws_can_fuse(n.r1[1][0], 1)) {
+        // refinement1_disp: the 1 -> 32 convolution is recomputed inside the first block's staging (one launch less)
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[1][0], pred3, n.r1_first[1], rc_, B, H, W, st));
+    } else {
+        LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(pred3, 1, n.r1_first[1], rb, B, H, W, st));
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][0], rb, rc_, B, H, W, st));
+    }
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][1], rc_, rb, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][2], rb, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][3], rc_, rb, B, H, W, st));

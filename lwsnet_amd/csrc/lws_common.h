@@ -188,6 +188,9 @@ int launch_conv2d_pair(const Conv2dLayer &a, const Conv2dLayer &b, const float *
                        int H, int W, hipStream_t st, const float *in2 = nullptr, int n1 = 0);
 int launch_ref_first(const float *in, int cin, const float *w, float *out, int B, int H, int W, hipStream_t st);
 int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, int W, hipStream_t st);
+bool ref_first_dws_can_fuse(const RefDws &l, int cin);
+int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst, float *out, int B, int H, int W,
+                         hipStream_t st);
 int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, float *out, int B, int H, int W,
                       hipStream_t st);
 int launch_ref_last(const float *in, const float *w, const float *pred3, float *out, int B, int H, int W, hipStream_t st);

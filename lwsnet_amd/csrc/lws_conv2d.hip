@@ -412,7 +412,16 @@ __device__ __forceinline__ RefTile ref_tile(int dil, int nbx, int nby, int tile_
 // plane strides of 186 / 130 float4 put the 8 planes of one pixel 40 / 8 dwords apart mod 64: conflict-free b128.
 constexpr int DWS_SA = 186, DWS_SB = 130;
 
-__global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, const float *__restrict__ bn_s,
+// FIRST = true fuses the 1 -> 32 convolution in front of the block (refinement1_disp[0], submodules.py:291-293: 3x3,
+// pad 1, no BN/ReLU) into the staging: `in` is then the [B,1,H,W] disparity map and wf its [tap][32] weights; every
+// halo pixel's 32 channels are recomputed from a dense (RH_Y-1)*dil+3 x (RH_X-1)*dil+3 image window held in LDS
+// (aliased onto sB, which is not live yet) with the same tap-ascending fmaf chain as k_ref_first.  Requires dil = 2.
+constexpr int DWS_FD = 2, DWS_FR = (RH_Y - 1) * DWS_FD + 3, DWS_FC = (RH_X - 1) * DWS_FD + 3;
+static_assert(DWS_FR * DWS_FC <= 1024 && DWS_FR * DWS_FC <= 8 * DWS_SB * 4, "first-conv window must fit 4 loads/thread and sB");
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, const float *__restrict__ wf,
+                                                 const float *__restrict__ bn_s,
                                                  const float *__restrict__ bn_t, const float *__restrict__ dw,   // [tap][32]
                                                  const float4 *__restrict__ pwpk,                              // [q][mt][lane]
                                                  float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt)
@@ -421,7 +430,6 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
     __shared__ float4 sB[8 * DWS_SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RefTile t = ref_tile(dil, nbx, nby);
-    const float *inb = in + (int64_t)t.b * H * W * 32;
     LWS_STAMPK(5, 0);
 
     const int c4 = tid & 7;
@@ -432,14 +440,60 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
     constexpr int NPX = RH_Y * RH_X, SITER = (NPX * 8 + 255) / 256;
     float4 c[SITER];
     bool okv[SITER];
+    if (FIRST) {
+        float *sImg = reinterpret_cast<float *>(sB);
+        const float *img = in + (int64_t)t.b * H * W;
+        const int gy0 = t.Y0 - DWS_FD - 1, gx0 = t.X0 - DWS_FD - 1;
+        float iv[4];
+        bool iok[4];
 #pragma unroll
-    for (int i = 0; i < SITER; ++i) {
-        const int hp = (tid >> 3) + 32 * i;
-        const int hy = hp / RH_X, hx = hp - hy * RH_X;
-        const int gy = t.Y0 + (hy - 1) * dil, gx = t.X0 + (hx - 1) * dil;
-        okv[i] = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const int off = okv[i] ? (gy * W + gx) * 32 + c4 * 4 : 0;      // one image < 2^31 floats
-        c[i] = *reinterpret_cast<const float4 *>(inb + off);
+        for (int k = 0; k < 4; ++k) {
+            const int r = tid + 256 * k;
+            const int ry = r / DWS_FC, rx = r - ry * DWS_FC;
+            const int gy = gy0 + ry, gx = gx0 + rx;
+            iok[k] = r < DWS_FR * DWS_FC && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            iv[k] = img[iok[k] ? gy * W + gx : 0];
+        }
+        float4 wq[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wq[tap] = *reinterpret_cast<const float4 *>(wf + tap * 32 + c4 * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid + 256 * k < DWS_FR * DWS_FC) sImg[tid + 256 * k] = iok[k] ? iv[k] : 0.0f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int hp = (tid >> 3) + 32 * i;
+            const int hy = hp / RH_X, hx = hp - hy * RH_X;
+            const int gy = t.Y0 + (hy - 1) * DWS_FD, gx = t.X0 + (hx - 1) * DWS_FD;
+            okv[i] = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float *sp = sImg + (hp < NPX ? (hy * DWS_FD) * DWS_FC + hx * DWS_FD : 0);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float v = sp[kh * DWS_FC + kw];
+                    const float4 w = wq[kh * 3 + kw];
+                    a.x = fmaf(v, w.x, a.x);
+                    a.y = fmaf(v, w.y, a.y);
+                    a.z = fmaf(v, w.z, a.z);
+                    a.w = fmaf(v, w.w, a.w);
+                }
+            c[i] = a;
+        }
+        __syncthreads();          // sImg (= sB) is dead from here; sB is first written after the next barrier anyway
+    } else {
+        const float *inb = in + (int64_t)t.b * H * W * 32;
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int hp = (tid >> 3) + 32 * i;
+            const int hy = hp / RH_X, hx = hp - hy * RH_X;
+            const int gy = t.Y0 + (hy - 1) * dil, gx = t.X0 + (hx - 1) * dil;
+            okv[i] = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int off = okv[i] ? (gy * W + gx) * 32 + c4 * 4 : 0;      // one image < 2^31 floats
+            c[i] = *reinterpret_cast<const float4 *>(inb + off);
+        }
     }
     // pointwise A fragments and this thread's depthwise weights (its channel group is fixed)
     float4 aw[2][2];
@@ -736,8 +790,28 @@ int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, i
 {
     const int nbx = cdiv(W, RT_X * l.dil), nby = cdiv(H, RT_Y * l.dil);
     dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
-    hipLaunchKernelGGL(k_ref_dws, grid, block, 0, st, in, l.bn_s, l.bn_t, l.dw, reinterpret_cast<const float4 *>(l.pw),
-                       out, H, W, l.dil, nbx, nby, use_wt_stores((size_t)B * H * W * 128));
+    hipLaunchKernelGGL(k_ref_dws<false>, grid, block, 0, st, in, (const float *)nullptr, l.bn_s, l.bn_t, l.dw,
+                       reinterpret_cast<const float4 *>(l.pw), out, H, W, l.dil, nbx, nby,
+                       use_wt_stores((size_t)B * H * W * 128));
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+// 1 -> 32 first convolution + the first depthwise-separable block in one launch (disparity branch of refinement1)
+bool ref_first_dws_can_fuse(const RefDws &l, int cin) { return cin == 1 && l.dil == DWS_FD; }
+
+int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst, float *out, int B, int H, int W,
+                         hipStream_t st)
+{
+    if (!ref_first_dws_can_fuse(l, 1)) {
+        set_error("ref_first_dws: dilation %d unsupported", l.dil);
+        return LWS_ERR_INVALID;
+    }
+    const int nbx = cdiv(W, RT_X * l.dil), nby = cdiv(H, RT_Y * l.dil);
+    dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
+    hipLaunchKernelGGL(k_ref_dws<true>, grid, block, 0, st, img, wfirst, l.bn_s, l.bn_t, l.dw,
+                       reinterpret_cast<const float4 *>(l.pw), out, H, W, l.dil, nbx, nby,
+                       use_wt_stores((size_t)B * H * W * 128));
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
