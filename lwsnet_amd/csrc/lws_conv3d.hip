@@ -178,38 +178,41 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
     LWS_STAMPK(1, 0);
 
     // ---- stage the halo tile: one item = (voxel, 16-channel group) = 64 contiguous bytes.  All global loads
-    //      of a thread are issued first (SITER x 4 float4 in flight), then transposed 4x4 and written to LDS.
-    {
-        float4 c[SITER][4];
+    //      of a thread are issued first (SITER x 4 float4 in flight), then transposed 4x4 and written to LDS --
+    //      in two phases: the taps kd = 0 only read halo slices [0, TD), i.e. the items of iterations i < P1;
+    //      the rest (iterations P1..SITER-1, still in flight) is written after the kd = 0 taps, under their MFMAs.
+    constexpr int P1 = (TD * HY * HX * Q + NT - 1) / NT < SITER ? (TD * HY * HX * Q + NT - 1) / NT : SITER;
+    float4 c[SITER][4];
+    bool okv[SITER];
 #pragma unroll
-        for (int i = 0; i < SITER; ++i) {
-            const int it = tid + i * NT;
-            const int q = it % Q, v = it / Q;
-            const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
-            const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-            const bool ok = it < Cfg::ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
-            // unconditional loads (padding / surplus items read voxel 0 and are zeroed below): no branch per load
-            const float4 *src = reinterpret_cast<const float4 *>(inb + (ok ? (((int64_t)gd * h + gy) * w + gx) * C3 + q * 16 : 0));
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            c[i][0] = src[0];
-            c[i][1] = src[1];
-            c[i][2] = src[2];
-            c[i][3] = src[3];
-            if (!ok) c[i][0] = c[i][1] = c[i][2] = c[i][3] = z;
-        }
-#pragma unroll
-        for (int i = 0; i < SITER; ++i) {
-            const int it = tid + i * NT;
-            if (it < Cfg::ITEMS) {
-                const int q = it % Q, v = it / Q;
-                float4 *dst = reinterpret_cast<float4 *>(lds + v * VS + q * 16);
-                dst[0] = make_float4(c[i][0].x, c[i][1].x, c[i][2].x, c[i][3].x);
-                dst[1] = make_float4(c[i][0].y, c[i][1].y, c[i][2].y, c[i][3].y);
-                dst[2] = make_float4(c[i][0].z, c[i][1].z, c[i][2].z, c[i][3].z);
-                dst[3] = make_float4(c[i][0].w, c[i][1].w, c[i][2].w, c[i][3].w);
-            }
-        }
+    for (int i = 0; i < SITER; ++i) {
+        const int it = tid + i * NT;
+        const int q = it % Q, v = it / Q;
+        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        okv[i] = it < Cfg::ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        // unconditional loads (padding / surplus items read voxel 0 and are zeroed below): no branch per load
+        const float4 *src = reinterpret_cast<const float4 *>(inb + (okv[i] ? (((int64_t)gd * h + gy) * w + gx) * C3 + q * 16 : 0));
+        c[i][0] = src[0];
+        c[i][1] = src[1];
+        c[i][2] = src[2];
+        c[i][3] = src[3];
     }
+    auto stage_write = [&](int i) {
+        const int it = tid + i * NT;
+        if (it < Cfg::ITEMS) {
+            const int q = it % Q, v = it / Q;
+            float4 *dst = reinterpret_cast<float4 *>(lds + v * VS + q * 16);
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 c0 = okv[i] ? c[i][0] : z, c1 = okv[i] ? c[i][1] : z, c2 = okv[i] ? c[i][2] : z, c3 = okv[i] ? c[i][3] : z;
+            dst[0] = make_float4(c0.x, c1.x, c2.x, c3.x);
+            dst[1] = make_float4(c0.y, c1.y, c2.y, c3.y);
+            dst[2] = make_float4(c0.z, c1.z, c2.z, c3.z);
+            dst[3] = make_float4(c0.w, c1.w, c2.w, c3.w);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < P1; ++i) stage_write(i);
 
     // weights of this wave: [tap][q][mt][lane] float4, mt in [wm*MTW, (wm+1)*MTW); the packed array holds one
     // extra all-zero tap so that the "next tap" prefetch never needs a bounds check
@@ -250,6 +253,15 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
     for (int kdh = 0; kdh < 9; ++kdh) {
         const int kd = kdh / 3, kh = kdh - kd * 3;
         const int base = (kd * HY + kh) * HX * VS;
+        if (P1 < SITER && kdh == 3) {
+            // phase 2 of the staging: halo slices TD, TD+1 (first read by kd = 1); the fragment prefetched at the end
+            // of iteration 2 may predate these writes, so it is read again
+#pragma unroll
+            for (int i = P1; i < SITER; ++i) stage_write(i);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RW; ++r) bbuf[0][r] = *reinterpret_cast<const float4 *>(rptr[r] + base);
+        }
         // first fragment offset of the NEXT (kd,kh) iteration (clamped for the last one: the prefetch is unused)
         const int kn = kdh < 8 ? kdh + 1 : 8;
         const int base_n = ((kn / 3) * HY + (kn % 3)) * HX * VS;
@@ -388,32 +400,34 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
 
     // ---- stage: one item = half a voxel (4 channels, 16 B); scatter into 4 channel planes.  Static trip count:
     //      all global loads of a thread are issued before the first LDS write (one memory round trip, not SITER).
-    {
-        constexpr int ITEMS = Cfg::NVOX * 2, SITER = (ITEMS + 255) / 256;
-        float4 c[SITER];
-        bool okv[SITER];
+    //      Two phases as in k_conv3d_mid16: iterations i < P1 cover halo slices [0, TD) (all the kd = 0 taps read);
+    //      the rest is written to LDS after the kd = 0 taps.
+    constexpr int ITEMS = Cfg::NVOX * 2, SITER = (ITEMS + 255) / 256;
+    constexpr int P1 = (TD * HY * HX * 2 + 255) / 256 < SITER ? (TD * HY * HX * 2 + 255) / 256 : SITER;
+    float4 c[SITER];
+    bool okv[SITER];
 #pragma unroll
-        for (int i = 0; i < SITER; ++i) {
-            const int it = tid + i * 256;
-            const int half = it & 1, v = it >> 1;
-            const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
-            const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-            okv[i] = it < ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
-            c[i] = *reinterpret_cast<const float4 *>(inb + (okv[i] ? (((int64_t)gd * h + gy) * w + gx) * 8 + half * 4 : 0));
-        }
-#pragma unroll
-        for (int i = 0; i < SITER; ++i) {
-            const int it = tid + i * 256;
-            if (it < ITEMS) {
-                const float4 v4 = okv[i] ? c[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                float *dst = lds + ((it & 1) * 4) * PS + (it >> 1);
-                dst[0] = v4.x;
-                dst[PS] = v4.y;
-                dst[2 * PS] = v4.z;
-                dst[3 * PS] = v4.w;
-            }
-        }
+    for (int i = 0; i < SITER; ++i) {
+        const int it = tid + i * 256;
+        const int half = it & 1, v = it >> 1;
+        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        okv[i] = it < ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        c[i] = *reinterpret_cast<const float4 *>(inb + (okv[i] ? (((int64_t)gd * h + gy) * w + gx) * 8 + half * 4 : 0));
     }
+    auto stage_write = [&](int i) {
+        const int it = tid + i * 256;
+        if (it < ITEMS) {
+            const float4 v4 = okv[i] ? c[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float *dst = lds + ((it & 1) * 4) * PS + (it >> 1);
+            dst[0] = v4.x;
+            dst[PS] = v4.y;
+            dst[2 * PS] = v4.z;
+            dst[3 * PS] = v4.w;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < P1; ++i) stage_write(i);
     __syncthreads();
     LWS_STAMPK(2, 1);
 
@@ -428,7 +442,12 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
     }
 
 #pragma unroll
-    for (int kd = 0; kd < 3; ++kd)
+    for (int kd = 0; kd < 3; ++kd) {
+        if (kd == 1 && P1 < SITER) {
+#pragma unroll
+            for (int i = P1; i < SITER; ++i) stage_write(i);
+            __syncthreads();
+        }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -443,6 +462,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
                         acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], bv, acc[r], 0, 0, 0);
                     }
                 }
+    }
 
     LWS_STAMPK(2, 2);
     // ---- epilogue: row i = 4*(lane>>4) + reg -> xpar = (lane>>4)>>1, cout = 4*((lane>>4)&1) + reg ----
