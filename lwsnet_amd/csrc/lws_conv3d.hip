@@ -64,6 +64,9 @@ __global__ __launch_bounds__(256) void k_conv3d_first(const float *__restrict__ 
     const int y = (int)((v / w) % h);
     const int d = (int)(v / ((int64_t)w * h));
     const float *cb = cost + (int64_t)b * vol;
+    // epilogue BatchNorm, loaded together with the taps
+    const float4 sa = *reinterpret_cast<const float4 *>(bn_s + grp * 8), sb = *reinterpret_cast<const float4 *>(bn_s + grp * 8 + 4);
+    const float4 ta = *reinterpret_cast<const float4 *>(bn_t + grp * 8), tb = *reinterpret_cast<const float4 *>(bn_t + grp * 8 + 4);
     float a[27];
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd)
@@ -92,8 +95,6 @@ __global__ __launch_bounds__(256) void k_conv3d_first(const float *__restrict__ 
         acc[6] = fmaf(a[tap], w1.z, acc[6]);
         acc[7] = fmaf(a[tap], w1.w, acc[7]);
     }
-    const float4 sa = *reinterpret_cast<const float4 *>(bn_s + grp * 8), sb = *reinterpret_cast<const float4 *>(bn_s + grp * 8 + 4);
-    const float4 ta = *reinterpret_cast<const float4 *>(bn_t + grp * 8), tb = *reinterpret_cast<const float4 *>(bn_t + grp * 8 + 4);
     float4 *out = reinterpret_cast<float4 *>(act + ((int64_t)b * vol + v) * C3 + grp * 8);
     out[0] = make_float4(bn_relu(acc[0], sa.x, ta.x), bn_relu(acc[1], sa.y, ta.y), bn_relu(acc[2], sa.z, ta.z),
                          bn_relu(acc[3], sa.w, ta.w));
@@ -211,6 +212,14 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
             dst[3] = make_float4(c0.w, c1.w, c2.w, c3.w);
         }
     };
+    // next layer's BatchNorm of this lane's output channels: loaded here, behind the halo loads, so that the epilogue
+    // does not start with an exposed L2 round trip
+    float4 es[MTW], et[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        es[mt] = *reinterpret_cast<const float4 *>(bn_s + (wm * MTW + mt) * 16 + 4 * g);
+        et[mt] = *reinterpret_cast<const float4 *>(bn_t + (wm * MTW + mt) * 16 + 4 * g);
+    }
 #pragma unroll
     for (int i = 0; i < P1; ++i) stage_write(i);
 
@@ -325,8 +334,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
                 const int cb = (wm * MTW + mt) * 16 + 4 * g;
-                const float4 s = *reinterpret_cast<const float4 *>(bn_s + cb);
-                const float4 t = *reinterpret_cast<const float4 *>(bn_t + cb);
+                const float4 s = es[mt], t = et[mt];
                 float4 v;
                 v.x = bn_relu(acc[r][mt][0], s.x, t.x);
                 v.y = bn_relu(acc[r][mt][1], s.y, t.y);
@@ -386,6 +394,11 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
     const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * 8;
     LWS_STAMPK(2, 0);
+
+    // next layer's BatchNorm of this lane's 4 output channels (needed only by the epilogue; loaded early)
+    const int xpar = g >> 1, cb = 4 * (g & 1);
+    const float4 es8 = *reinterpret_cast<const float4 *>(bn_s + cb);
+    const float4 et8 = *reinterpret_cast<const float4 *>(bn_t + cb);
 
     // 72 A fragments of this lane as 18 float4 ([step/4][lane][4]): 18 wide loads instead of 72 dword loads
     float wa[72];
@@ -467,10 +480,8 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
     LWS_STAMPK(2, 2);
     // ---- epilogue: row i = 4*(lane>>4) + reg -> xpar = (lane>>4)>>1, cout = 4*((lane>>4)&1) + reg ----
     float *outb = out + (int64_t)b * D * h * w * 8;
-    const int xpar = g >> 1, cb = 4 * (g & 1);
     const int gx = x0 + 2 * n + xpar;
-    const float4 s = *reinterpret_cast<const float4 *>(bn_s + cb);
-    const float4 t = *reinterpret_cast<const float4 *>(bn_t + cb);
+    const float4 s = es8, t = et8;
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         const int row = wave * RW + r;
