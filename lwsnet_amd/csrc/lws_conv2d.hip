@@ -588,13 +588,14 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
 // channels-last maps are staged side by side.  fp32-MFMA implicit GEMM, K = 9 taps x 64 channels = 144 MFMAs per
 // accumulator; weights streamed from L2 in fragment order one step ahead (same scheme as k_conv3d_mid16).
 // =============================================================================================
-template <int TY>   // tile rows (4 waves: TY/4 rows each)
-__global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ inL, const float *__restrict__ inD,
+template <int TY, int NW>   // tile rows, waves per workgroup (TY/NW rows each)
+__global__ __launch_bounds__(64 * NW) void k_ref_conv64(const float *__restrict__ inL, const float *__restrict__ inD,
                                                     const float *__restrict__ bn_s, const float *__restrict__ bn_t,   // [64]
                                                     const float4 *__restrict__ wpk,   // [tap][qq][mt][lane]
                                                     float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt)
 {
-    constexpr int HY = TY + 2, NPX = HY * RH_X, RW = TY / 4;
+    constexpr int HY = TY + 2, NPX = HY * RH_X, RW = TY / NW, NT = 64 * NW;
+    static_assert(TY % NW == 0 && RW >= 1 && RW <= 4, "rows must split evenly over the waves");
     __shared__ __attribute__((aligned(16))) float sA[2 * NPX * RVS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RefTile t = ref_tile(dil, nbx, nby, TY);
@@ -602,13 +603,13 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
     LWS_STAMPK(6, 0);
 
     // stage: item = (tensor, halo pixel, 16-channel group) = 64 bytes
-    constexpr int ITEMS = 2 * NPX * 2, SITER = (ITEMS + 255) / 256;
+    constexpr int ITEMS = 2 * NPX * 2, SITER = (ITEMS + NT - 1) / NT;
     {
         float4 c[SITER][4];
         bool okv[SITER];
 #pragma unroll
         for (int i = 0; i < SITER; ++i) {          // unconditional, clamped loads first (see k_ref_dws)
-            const int it = tid + i * 256;
+            const int it = tid + i * NT;
             const int q = it & 1, hp = (it >> 1) % NPX, ten = (it >> 1) / NPX;
             const int hy = hp / RH_X, hx = hp % RH_X;
             const int gy = t.Y0 + (hy - 1) * dil, gx = t.X0 + (hx - 1) * dil;
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(256) void k_ref_conv64(const float *__restrict__ in
         }
 #pragma unroll
         for (int i = 0; i < SITER; ++i) {
-            const int it = tid + i * 256;
+            const int it = tid + i * NT;
             if (it < ITEMS) {
                 const int q = it & 1, hp = (it >> 1) % NPX, ten = (it >> 1) / NPX;
                 const float4 *sp = reinterpret_cast<const float4 *>(bn_s + ten * 32 + q * 16);
@@ -824,24 +825,26 @@ int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, fl
         return e ? atoi(e) : 1;
     }();
     const int dil = 8;
-    // variant 1 (default): 8-row tiles, 2 rows per wave -- each streamed weight fragment feeds 8 MFMAs instead of 4
-    // (measured r01: 52 / 345 us at B = 1 / 8 vs 56 / 387 us for the 4-row tile, which fits 5 workgroups per CU)
-    if (variant == 1) {
-        constexpr int TY = 8;
-        const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, TY * dil);
-        dim3 grid(nbx * nby * dil * dil * B), block(256);
-        hipLaunchKernelGGL(k_ref_conv64<TY>, grid, block, 0, st, inL, inD, l.bn_s, l.bn_t,
-                           reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby,
-                           use_wt_stores((size_t)B * H * W * 128));
-    } else {
-        // 4-row tiles: 27 KB of LDS per workgroup -> 5 workgroups (5 waves per SIMD) share each CU's MFMA pipes
-        constexpr int TY = 4;
-        const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, TY * dil);
-        dim3 grid(nbx * nby * dil * dil * B), block(256);
-        hipLaunchKernelGGL(k_ref_conv64<TY>, grid, block, 0, st, inL, inD, l.bn_s, l.bn_t,
-                           reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby,
-                           use_wt_stores((size_t)B * H * W * 128));
+#define LWS_C64(TYv, NWv)                                                                                          \
+    {                                                                                                               \
+        const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, TYv * dil);                                              \
+        dim3 grid(nbx * nby * dil * dil * B), block(64 * NWv);                                                      \
+        hipLaunchKernelGGL((k_ref_conv64<TYv, NWv>), grid, block, 0, st, inL, inD, l.bn_s, l.bn_t,                   \
+                           reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby,                         \
+                           use_wt_stores((size_t)B * H * W * 128));                                                 \
     }
+    // variant 1 (default): 8-row tiles, 4 waves x 2 rows (46 KB LDS: 3 workgroups per CU)   50.5 / 349 us at B = 1 / 8
+    // variant 0: 4-row tiles, 4 waves x 1 row (27 KB: 5 per CU; a weight fragment feeds 2 MFMAs)  54.3 / 390 us
+    // variant 2: 4-row tiles, 2 waves x 2 rows                                                    66.2 / 403 us
+    // variant 3: 2-row tiles, 1 wave x 2 rows (18 KB: 8 per CU)                                   53.8 / 408 us
+    // (measured r01, 256x512; the floor is 31 / 246 us of fp32 MFMA issue)
+    switch (variant) {
+        case 0: LWS_C64(4, 4); break;
+        case 2: LWS_C64(4, 2); break;
+        case 3: LWS_C64(2, 1); break;
+        default: LWS_C64(8, 4); break;
+    }
+#undef LWS_C64
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
