@@ -145,6 +145,10 @@ typedef enum {
  * on by a hipEvent pair recorded on the launch stream (records are dropped, never blocking, beyond 65536
  * launches); -1 selects all classes.  class_mask == 0: stop.  Either way the accumulated records are cleared. */
 int lws_profile_enable(lws_handle h, int class_mask);
+/* After lws_profile_enable: lws_forward records events on every `every_n`-th call only (1 = every call).  Timing a
+ * kernel with its own begin / end events keeps the next dispatch from being queued behind it, so bracketing every
+ * launch of a latency-bound step perturbs the step; sampling bounds that cost.  Reset to 1 by lws_profile_enable. */
+int lws_profile_sample(lws_handle h, int every_n);
 /* Synchronises the recorded events and returns, per kernel class, the summed device time in
  * milliseconds and the number of launches.  Both arrays have LWS_KC_COUNT entries. */
 int lws_profile_read(lws_handle h, double *total_ms, int64_t *launches);

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "lws_refine": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lws_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp * 4, _vp]),
     "lws_profile_enable": (_i, [_vp, _i]),
+    "lws_profile_sample": (_i, [_vp, _i]),
     "lws_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), c_int64_p]),
     "lws_kernel_class_name": (ctypes.c_char_p, [_i]),
 }

@@ -273,7 +273,7 @@ struct SlabBuilder {
 };
 
 struct Net2dOffsets {
-    struct L { size_t w, s, t; bool bn; };
+    struct L { size_t w, wp, s, t; bool bn; };
     L fe[12];
     size_t r1_first[2];
     struct D { size_t s, t, dw, pw; };
@@ -331,6 +331,17 @@ static void build_net2d(const lws_ctx *h, std::vector<float> &slab, Net2dOffsets
                         wt[(((size_t)tap * 4 + co / cpt) * d.cin + ci) * cpt + co % cpt] =
                             d.tr ? w[((size_t)ci * d.cout + co) * 9 + tap] : w[((size_t)co * d.cin + ci) * 9 + tap];
             o.fe[i].w = sb.put(wt);
+            o.fe[i].wp = 0;
+            const int G = conv2d_pair_groups(i);      // second copy in the group count the pair kernel uses
+            if (G > 0 && !d.tr) {
+                const int cpg = d.cout / G;
+                std::vector<float> wq((size_t)9 * d.cin * d.cout);
+                for (int co = 0; co < d.cout; ++co)
+                    for (int ci = 0; ci < d.cin; ++ci)
+                        for (int tap = 0; tap < 9; ++tap)
+                            wq[(((size_t)tap * G + co / cpg) * d.cin + ci) * cpg + co % cpg] = w[((size_t)co * d.cin + ci) * 9 + tap];
+                o.fe[i].wp = sb.put(wq);
+            }
         }
         o.fe[i].bn = d.bn;
         if (d.bn) {
@@ -379,6 +390,8 @@ static void bind_net2d(lws_ctx *h, const Net2dOffsets &o)
         l.cin = d.cin; l.cout = d.cout; l.stride = d.stride; l.pad = d.pad; l.dil = d.dil;
         l.transposed = d.tr; l.relu = d.relu;
         l.w = h->params + o.fe[i].w;
+        l.pair_groups = conv2d_pair_groups(i);
+        l.w_pair = l.pair_groups > 0 ? h->params + o.fe[i].wp : nullptr;
         l.bn_s = d.bn ? h->params + o.fe[i].s : nullptr;
         l.bn_t = d.bn ? h->params + o.fe[i].t : nullptr;
     }
@@ -656,7 +669,17 @@ int lws_profile_enable(lws_handle h, int class_mask)
 {
     LWS_CHECK_ARG(h, "lws_profile_enable: null handle");
     prof_clear(h);
-    h->prof_mask = (unsigned)class_mask;
+    h->prof_mask = h->prof_mask_cfg = (unsigned)class_mask;
+    h->prof_every = 1;
+    h->prof_calls = 0;
+    return LWS_OK;
+}
+
+int lws_profile_sample(lws_handle h, int every_n)
+{
+    LWS_CHECK_ARG(h && every_n >= 1, "lws_profile_sample: every_n must be >= 1");
+    h->prof_every = every_n;
+    h->prof_calls = 0;
     return LWS_OK;
 }
 
@@ -926,6 +949,12 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     rc = ensure_ws(h, L.total_all);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    // profiler sampling (lws_profile_sample): only every n-th forward call records events
+    struct MaskGuard {
+        lws_ctx *h;
+        ~MaskGuard() { h->prof_mask = h->prof_mask_cfg; }
+    } mask_guard{h};
+    h->prof_mask = (h->prof_every <= 1 || h->prof_calls++ % (unsigned)h->prof_every == 0) ? h->prof_mask_cfg : 0u;
     // refinement1_left depends on the left image only: it runs on a side stream, concurrently with the feature
     // extractor and the three volume stages, and joins before the rest of the refinement (speed only).
     if (!h->side) {

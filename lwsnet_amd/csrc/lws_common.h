@@ -56,7 +56,7 @@ static inline int use_wt_stores(size_t out_bytes) { return out_bytes <= ((size_t
 // Diagnostic builds only (LWS_EXTRA_FLAGS="-DLWS_STAMPS=<kernel id>"; tools/stamps.py): every workgroup of the selected
 // kernel stores s_memtime stamps of its phases in a per-translation-unit buffer.  The shipped library compiles
 // LWS_STAMPK to nothing.  Kernel ids: 1 mid16, 2 mid8, 3 conv3d_last, 4 conv3d_first, 5 ref_dws, 6 ref_conv64,
-// 7 conv2d_nchw, 8 ref_first, 9 ref_last, 10 volume_warp, 11 volume_shift, 12 softargmin_upsample, 13 conv2d_pair.
+// 7 conv2d_nchw, 8 ref_first, 9 ref_last, 10 volume_warp, 11 volume_shift, 12 softargmin_upsample, 13..16 conv2d_pair (dres0, dres1, conv1+2, conv3+4).
 #ifdef LWS_STAMPS
 #define LWS_DEFINE_STAMPS(tu)                                                                                      \
     __device__ unsigned long long g_stamps_##tu[4096 * 8];                                                         \
@@ -101,6 +101,8 @@ struct Conv2dLayer {
     int cin = 0, cout = 0, stride = 1, pad = 1, dil = 1;
     bool transposed = false, relu = false;
     float *w = nullptr, *bn_s = nullptr, *bn_t = nullptr;
+    float *w_pair = nullptr;   // [tap][pair_groups][cin][cout/pair_groups] for k_conv2d_pair (layers 0..7 only)
+    int pair_groups = 0;
 };
 
 // Refinement: BatchNorm(32) -> ReLU -> depthwise 3x3 (dil) -> pointwise 32->32
@@ -134,7 +136,10 @@ struct lws_prof_rec {
 
 struct lws_ctx {
     lws_config cfg;
-    unsigned prof_mask = 0;                  // kernel classes being timed
+    unsigned prof_mask = 0;                  // kernel classes being timed in the current call
+    unsigned prof_mask_cfg = 0;              // ... as configured by lws_profile_enable
+    int prof_every = 1;                      // lws_profile_sample: lws_forward records events on every n-th call only
+    unsigned prof_calls = 0;
     std::vector<lws_prof_rec> prof;          // records of the current session
     std::vector<hipEvent_t> evt_pool;        // events available for reuse
     int device = 0;
@@ -184,6 +189,7 @@ int launch_conv3d_last(const Stage3d &s, const float *act_in, const float *cost_
 // 2D networks (lws_conv2d.hip)
 int launch_conv2d_nchw(const Conv2dLayer &l, const float *in, const float *res, float *out, int N, int H, int W,
                        hipStream_t st, const float *in2 = nullptr, int n1 = 0);
+int conv2d_pair_groups(int layer);
 int launch_conv2d_pair(const Conv2dLayer &a, const Conv2dLayer &b, const float *in, const float *res, float *out, int N,
                        int H, int W, hipStream_t st, const float *in2 = nullptr, int n1 = 0);
 int launch_ref_first(const float *in, int cin, const float *w, float *out, int B, int H, int W, hipStream_t st);

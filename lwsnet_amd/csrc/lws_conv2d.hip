@@ -164,53 +164,87 @@ int launch_conv2d_nchw(const Conv2dLayer &l, const float *in, const float *res, 
 }
 
 // =============================================================================================
-// Two chained feature-extractor layers in one launch: A (3x3, stride sA, dilation dA, BN, ReLU?) followed by B (3x3,
-// stride 1, dilation dB, BN?, + residual?, ReLU?).  The workgroup owns an 8 x 8 tile of B's output; A is evaluated on
-// the (8 + 2 dB)^2 region B needs (its values outside A's output map are B's zero padding) and kept in LDS, so the
-// intermediate map never goes to HBM and one launch (~7 us of fixed cost at batch 1) disappears.  Every layer keeps
-// its own arithmetic (same fma chains), so the result is bit-identical to running the two kernels back to back.
+// Two chained feature-extractor layers in one launch: A (3x3, stride SA, dilation DA = pad, BN, ReLU?) followed by B
+// (3x3, stride 1, dilation DB = pad, BN?, + residual?, ReLU?).  The workgroup owns an 8 x 8 tile of B's output; A is
+// evaluated on the MR x MR region B needs (MR = 8 + 2 DB; its values outside A's output map are B's zero padding) and
+// kept in LDS, so the intermediate map never goes to HBM and one launch disappears.  Every layer keeps its own
+// arithmetic (same fma chains), so the result is bit-identical to running the two kernels back to back.
+//
+// These layers hold a few hundred fmas per pixel: they are latency-bound (LDS reads, scalar weight loads), so
+// the kernel is organised for parallelism, not reuse.  All geometry is compile time.  NW waves per workgroup:
+//   phase 1  every thread loads ceil(CIN RH^2 / NT) input values, all in flight at once;
+//   phase 2  the MR^2 pixels of A are spread over WGA waves and its CM output channels over GA = NW / WGA groups of
+//            waves, so the whole region is ONE pass (weights [tap][GA][CIN][CM/GA], wave-uniform -> scalar loads);
+//   phase 3  wave = COUT/NW output channels of B for the 64 tile pixels (weights [tap][NW][CM][COUT/NW]).
+// NW = 4 for the 1/2-resolution pairs (4 workgroups per CU), NW = 16 for the 1/4 and 1/8 pairs, whose grids have
+// fewer workgroups than the chip has CUs.
 // =============================================================================================
-template <int CIN, int CM, int COUT>
-__global__ __launch_bounds__(256) void k_conv2d_pair(const float *__restrict__ in, const float *__restrict__ in2, int n1,
-                                                     const float *__restrict__ wA, const float *__restrict__ sA_,
-                                                     const float *__restrict__ tA_, int reluA,
-                                                     const float *__restrict__ wB, const float *__restrict__ sB_,
-                                                     const float *__restrict__ tB_, const float *__restrict__ res,
-                                                     int reluB, float *__restrict__ out, int H, int W, int HA, int WA,
-                                                     int strideA, int padA, int dilA, int dilB, int RH, int RWp, int MR,
-                                                     int MRp)
+template <int CIN, int CM, int COUT, int SA, int DA, int DB, int NW>
+struct PairCfg {
+    static constexpr int NT = 64 * NW;
+    static constexpr int MR = 8 + 2 * DB, MRp = MR | 1;
+    static constexpr int RH = (MR - 1) * SA + 2 * DA + 1, RWp = RH | 1;
+    static constexpr int WGA_ = (MR * MR + 63) / 64;                                  // waves needed for one pass over A's region
+    static constexpr int WGA = WGA_ <= 1 ? 1 : WGA_ <= 2 ? 2 : WGA_ <= 4 ? 4 : WGA_ <= 8 ? 8 : 16;
+    static constexpr int GA = NW / WGA, CPA = CM / GA, CPB = COUT / NW;
+    static constexpr int ITEMS = CIN * RH * RH, SITER = (ITEMS + NT - 1) / NT;
+    static constexpr int LDS_FLOATS = CIN * RH * RWp + CM * MR * MRp;
+    static_assert(WGA <= NW && NW % WGA == 0 && CM % GA == 0 && COUT % NW == 0 && CPA >= 1 && CPB >= 1, "bad pair geometry");
+    static_assert(WGA * 64 >= MR * MR, "phase 2 must be one pass");
+};
+
+template <int CIN, int CM, int COUT, int SA, int DA, int DB, int NW>
+__global__ __launch_bounds__(64 * NW) void k_conv2d_pair(const float *__restrict__ in, const float *__restrict__ in2, int n1,
+                                                         const float *__restrict__ wA, const float *__restrict__ sA_,
+                                                         const float *__restrict__ tA_, int reluA,
+                                                         const float *__restrict__ wB, const float *__restrict__ sB_,
+                                                         const float *__restrict__ tB_, const float *__restrict__ res,
+                                                         int reluB, float *__restrict__ out, int H, int W, int HA, int WA)
 {
-    constexpr int CPA = CM / 4, CPB = COUT / 4;
+    using Cfg = PairCfg<CIN, CM, COUT, SA, DA, DB, NW>;
+    constexpr int NT = Cfg::NT, MR = Cfg::MR, MRp = Cfg::MRp, RH = Cfg::RH, RWp = Cfg::RWp, WGA = Cfg::WGA, GA = Cfg::GA,
+                  CPA = Cfg::CPA, CPB = Cfg::CPB, SITER = Cfg::SITER, RSZ = RH * RH;
     extern __shared__ float smem[];
     float *sIn = smem;                       // [CIN][RH][RWp]
     float *sMid = smem + CIN * RH * RWp;     // [CM][MR][MRp]
     const int b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ox0 = blockIdx.x * 8, oy0 = blockIdx.y * 8;
-    const int my0 = oy0 - dilB, mx0 = ox0 - dilB;                 // origin of the intermediate region (A-output coords)
-    const int iy0 = my0 * strideA - padA, ix0 = mx0 * strideA - padA;
+    const int my0 = oy0 - DB, mx0 = ox0 - DB;                     // origin of the intermediate region (A-output coords)
+    const int iy0 = my0 * SA - DA, ix0 = mx0 * SA - DA;           // pad == dilation for every layer of the extractor
     const int plane = H * W;
     const float *inb = b < n1 ? in + (int64_t)b * CIN * plane : in2 + (int64_t)(b - n1) * CIN * plane;
-    // phase 1: input region
-    const int rsz = RH * RH;
-    for (int r = tid; r < rsz; r += 256) {
-        const int ry = r / RH, rx = r - ry * RH;
-        const int gy = iy0 + ry, gx = ix0 + rx;
-        const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const float *src = inb + (ok ? gy * W + gx : 0);
-        float v[CIN];
+    constexpr int STAMP_ID = 13 + (CIN == 3 ? 0 : CM == 4 ? 1 : CIN == 8 ? 2 : 3);   // diagnostic builds only
+    LWS_STAMPK(STAMP_ID, 0);
+    // phase 1: input region, item = (channel, region pixel); unconditional clamped loads, masked afterwards
+    {
+        float v[SITER];
+        bool okv[SITER];
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) v[ci] = src[ci * plane];
-        float *dst = sIn + ry * RWp + rx;
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * NT;
+            const int ci = it / RSZ, r = it - ci * RSZ;
+            const int ry = r / RH, rx = r - ry * RH;
+            const int gy = iy0 + ry, gx = ix0 + rx;
+            okv[i] = it < Cfg::ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            v[i] = inb[okv[i] ? ci * plane + gy * W + gx : 0];
+        }
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) dst[ci * RH * RWp] = ok ? v[ci] : 0.0f;
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * NT;
+            const int ci = it / RSZ, r = it - ci * RSZ;
+            const int ry = r / RH, rx = r - ry * RH;
+            if (it < Cfg::ITEMS) sIn[(ci * RH + ry) * RWp + rx] = okv[i] ? v[i] : 0.0f;
+        }
     }
     __syncthreads();
-    // phase 2: layer A on the MR x MR region; wave = output-channel group of A
+    LWS_STAMPK(STAMP_ID, 1);
+    // phase 2: layer A on the MR x MR region
     {
-        const int coA = wave * CPA;
-        const int npx = MR * MR;
-        for (int p = lane; p < npx; p += 64) {
+        const int ga = wave / WGA;
+        const int coA = ga * CPA;
+        const int p = (wave - ga * WGA) * 64 + lane;
+        if (p < MR * MR) {
             const int my = p / MR, mx = p - my * MR;
             const int ay = my0 + my, ax = mx0 + mx;
             const bool valid = ay >= 0 && ay < HA && ax >= 0 && ax < WA;
@@ -220,8 +254,8 @@ __global__ __launch_bounds__(256) void k_conv2d_pair(const float *__restrict__ i
 #pragma unroll 3
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap - kh * 3;
-                const float *pp = sIn + (my * strideA + kh * dilA) * RWp + mx * strideA + kw * dilA;
-                const float *w = wA + (tap * 4 + wave) * CIN * CPA;
+                const float *pp = sIn + (my * SA + kh * DA) * RWp + mx * SA + kw * DA;
+                const float *w = wA + (tap * GA + ga) * CIN * CPA;
                 float v[CIN];
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) v[ci] = pp[ci * RH * RWp];
@@ -239,19 +273,25 @@ __global__ __launch_bounds__(256) void k_conv2d_pair(const float *__restrict__ i
         }
     }
     __syncthreads();
+    LWS_STAMPK(STAMP_ID, 2);
     // phase 3: layer B on the 8 x 8 tile; wave = output-channel group of B, lane = pixel
     const int tx = lane & 7, ty = lane >> 3;
     const int ox = ox0 + tx, oy = oy0 + ty;
     if (ox >= WA || oy >= HA) return;
     const int coB = wave * CPB;
+    const int oplane = HA * WA;
+    const int64_t o = ((int64_t)b * COUT + coB) * oplane + oy * WA + ox;
+    float rv[CPB];
+#pragma unroll
+    for (int c = 0; c < CPB; ++c) rv[c] = res != nullptr ? res[o + (int64_t)c * oplane] : 0.0f;   // in flight under the taps
     float acc[CPB];
 #pragma unroll
     for (int c = 0; c < CPB; ++c) acc[c] = 0.0f;
 #pragma unroll 3
     for (int tap = 0; tap < 9; ++tap) {
         const int kh = tap / 3, kw = tap - kh * 3;
-        const float *pp = sMid + (ty + kh * dilB) * MRp + tx + kw * dilB;
-        const float *w = wB + (tap * 4 + wave) * CM * CPB;
+        const float *pp = sMid + (ty + kh * DB) * MRp + tx + kw * DB;
+        const float *w = wB + (tap * NW + wave) * CM * CPB;
         float v[CM];
 #pragma unroll
         for (int ci = 0; ci < CM; ++ci) v[ci] = pp[ci * MR * MRp];
@@ -260,44 +300,55 @@ __global__ __launch_bounds__(256) void k_conv2d_pair(const float *__restrict__ i
 #pragma unroll
             for (int c = 0; c < CPB; ++c) acc[c] = fmaf(v[ci], w[ci * CPB + c], acc[c]);
     }
-    const int oplane = HA * WA;
-    const int64_t o = ((int64_t)b * COUT + coB) * oplane + oy * WA + ox;
 #pragma unroll
     for (int c = 0; c < CPB; ++c) {
         float v = acc[c];
         if (sB_ != nullptr) v = fmaf(v, sB_[coB + c], tB_[coB + c]);
-        if (res != nullptr) v = v + res[o + (int64_t)c * oplane];
+        if (res != nullptr) v = v + rv[c];
         if (reluB) v = fmaxf(v, 0.0f);
         out[o + (int64_t)c * oplane] = v;
     }
+    LWS_STAMPK(STAMP_ID, 3);
 }
 
-template <int CIN, int CM, int COUT>
+template <int CIN, int CM, int COUT, int SA, int DA, int DB, int NW>
 static int conv2d_pair_launch(const Conv2dLayer &a, const Conv2dLayer &b, const float *in, const float *in2, int n1,
                               const float *res, float *out, int N, int H, int W, int HA, int WA, hipStream_t st)
 {
-    const int MR = 8 + 2 * b.dil, MRp = MR | 1;
-    const int RH = (MR - 1) * a.stride + 2 * a.dil + 1, RWp = RH | 1;
-    const size_t lds = ((size_t)CIN * RH * RWp + (size_t)CM * MR * MRp) * sizeof(float);
-    static size_t attr_lds = 0;
-    if (lds > 48 * 1024 && lds > attr_lds) {
-        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv2d_pair<CIN, CM, COUT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
+    using Cfg = PairCfg<CIN, CM, COUT, SA, DA, DB, NW>;
+    if (a.w_pair == nullptr || b.w_pair == nullptr || a.pair_groups != Cfg::GA || b.pair_groups != NW) {
+        set_error("conv2d_pair: weights are not packed for this pair geometry");
+        return LWS_ERR_STATE;
     }
-    dim3 grid(cdiv(WA, 8), cdiv(HA, 8), N), block(256);
-    hipLaunchKernelGGL((k_conv2d_pair<CIN, CM, COUT>), grid, block, lds, st, in, in2, n1, a.w, a.bn_s, a.bn_t,
-                       a.relu ? 1 : 0, b.w, b.bn_s, b.bn_t, res, b.relu ? 1 : 0, out, H, W, HA, WA, a.stride, a.pad, a.dil,
-                       b.dil, RH, RWp, MR, MRp);
+    const size_t lds = (size_t)Cfg::LDS_FLOATS * sizeof(float);
+    static bool attr_done = false;
+    if (lds > 48 * 1024 && !attr_done) {
+        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv2d_pair<CIN, CM, COUT, SA, DA, DB, NW>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    dim3 grid(cdiv(WA, 8), cdiv(HA, 8), N), block(Cfg::NT);
+    hipLaunchKernelGGL((k_conv2d_pair<CIN, CM, COUT, SA, DA, DB, NW>), grid, block, lds, st, in, in2, n1, a.w_pair, a.bn_s,
+                       a.bn_t, a.relu ? 1 : 0, b.w_pair, b.bn_s, b.bn_t, res, b.relu ? 1 : 0, out, H, W, HA, WA);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
+}
+
+// Output-channel groups the pair kernel wants for layer i of the feature extractor (0..7: A, B, A, B, ...); the host
+// packs w_pair as [tap][groups][cin][cout/groups].
+int conv2d_pair_groups(int layer)
+{
+    static const int g[8] = {PairCfg<3, 4, 8, 2, 2, 4, 4>::GA,     4,  PairCfg<8, 4, 8, 1, 2, 2, 4>::GA,      4,
+                             PairCfg<8, 16, 16, 2, 1, 1, 16>::GA, 16, PairCfg<16, 16, 16, 2, 1, 1, 16>::GA, 16};
+    return layer >= 0 && layer < 8 ? g[layer] : 0;
 }
 
 // layer a (conv, BN) then layer b (conv stride 1, pad == dil) on N images [N,a.cin,H,W] -> [N,b.cout,HA,WA]
 int launch_conv2d_pair(const Conv2dLayer &a, const Conv2dLayer &b, const float *in, const float *res, float *out, int N,
                        int H, int W, hipStream_t st, const float *in2, int n1)
 {
-    if (a.transposed || b.transposed || b.stride != 1 || b.pad != b.dil || a.bn_s == nullptr || b.cin != a.cout) {
+    if (a.transposed || b.transposed || b.stride != 1 || b.pad != b.dil || a.pad != a.dil || a.bn_s == nullptr ||
+        b.cin != a.cout) {
         set_error("conv2d_pair: unsupported layer pair");
         return LWS_ERR_INVALID;
     }
@@ -306,12 +357,13 @@ int launch_conv2d_pair(const Conv2dLayer &a, const Conv2dLayer &b, const float *
         n1 = N;
     }
     const int HA = (H + 2 * a.pad - 2 * a.dil - 1) / a.stride + 1, WA = (W + 2 * a.pad - 2 * a.dil - 1) / a.stride + 1;
-#define LWS_C2P(CI, CMID, CO)                                  \
-    if (a.cin == CI && a.cout == CMID && b.cout == CO)         \
-        return conv2d_pair_launch<CI, CMID, CO>(a, b, in, in2, n1, res, out, N, H, W, HA, WA, st);
-    LWS_C2P(3, 4, 8) LWS_C2P(8, 4, 8) LWS_C2P(8, 16, 16) LWS_C2P(16, 16, 16)
+#define LWS_C2P(CI, CMID, CO, SA, DA, DB, NW)                                                             \
+    if (a.cin == CI && a.cout == CMID && b.cout == CO && a.stride == SA && a.dil == DA && b.dil == DB)    \
+        return conv2d_pair_launch<CI, CMID, CO, SA, DA, DB, NW>(a, b, in, in2, n1, res, out, N, H, W, HA, WA, st);
+    LWS_C2P(3, 4, 8, 2, 2, 4, 4) LWS_C2P(8, 4, 8, 1, 2, 2, 4) LWS_C2P(8, 16, 16, 2, 1, 1, 16) LWS_C2P(16, 16, 16, 2, 1, 1, 16)
 #undef LWS_C2P
-    set_error("conv2d_pair: unsupported channels %d -> %d -> %d", a.cin, a.cout, b.cout);
+    set_error("conv2d_pair: unsupported pair %d -> %d -> %d (stride %d, dilations %d, %d)", a.cin, a.cout, b.cout, a.stride,
+              a.dil, b.dil);
     return LWS_ERR_INVALID;
 }
 

@@ -1,7 +1,7 @@
 """Diagnostic: per-workgroup phase stamps (s_memtime, shader cycles) of one kernel.
 
     python tools/stamps.py <kernel> [batch]     # rebuilds the library with -DLWS_STAMPS=<id>, runs, prints medians
-kernels: mid16 mid8s2 mid8s3 last1 last3 first1 first3 dws conv64 feat ref_first ref_last warp2 warp3
+kernels: mid16 mid8s2 mid8s3 last1 last3 dws conv64 feat pair0..pair3 ref_last warp2 warp3
 Slots: 0..3 = phase boundaries as placed in the kernel source (LWS_STAMPK)."""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, '/root/repo')
@@ -10,7 +10,8 @@ KERNELS = {  # name: (stamp id, translation unit, driver, arg)
     "last1": (3, "conv3d", "stack", 0), "last3": (3, "conv3d", "stack", 2),
     
     "dws": (5, "conv2d", "refine", None), "conv64": (6, "conv2d", "refine", None),
-    "feat": (7, "conv2d", "feat", None), "ref_last": (9, "conv2d", "refine", None),
+    "feat": (7, "conv2d", "feat", None), "pair0": (13, "conv2d", "feat", None), "pair1": (14, "conv2d", "feat", None),
+    "pair2": (15, "conv2d", "feat", None), "pair3": (16, "conv2d", "feat", None), "ref_last": (9, "conv2d", "refine", None),
     "warp2": (10, "volume", "stages", None), "warp3": (10, "volume", "stages", None),
 }
 what = sys.argv[1]
