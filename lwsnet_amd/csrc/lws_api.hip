@@ -94,7 +94,7 @@ static void fold_bn(const lws_ctx *h, const std::string &p, std::vector<float> &
 }
 
 struct WsLayout {
-    size_t act_a, act_b, cost_raw, cost_out, low, total;   // float offsets (hot path)
+    size_t act_a, act_b, cost_raw, cost_out, low[3], total;   // float offsets (hot path); low[s]: stage s low-res disparity
     // 2D networks: feature-extractor maps for N = 2B images, refinement ping-pong maps
     size_t fe_a0, fe_o, fe_a2, fe_o2, fe_c1, fe_pre, fe_c3, fe_f8, fe_f4, fe_o3, fe_cls, fe_f2;
     size_t r_a, r_b, r_c;
@@ -126,8 +126,10 @@ static WsLayout ws_layout(const lws_ctx *h, int B, int H, int W)
     L.act_b = L.act_a + al(max_act);
     L.cost_raw = L.act_b + al(max_act);
     L.cost_out = L.cost_raw + al(max_cost);
-    L.low = L.cost_out + al(max_cost);
-    L.total = L.low + al((size_t)B * (H / 2) * (W / 2));
+    L.low[0] = L.cost_out + al(max_cost);
+    L.low[1] = L.low[0] + al((size_t)B * (H / 8) * (W / 8));
+    L.low[2] = L.low[1] + al((size_t)B * (H / 4) * (W / 4));
+    L.total = L.low[2] + al((size_t)B * (H / 2) * (W / 2));
     const size_t N = 2 * (size_t)B, p2 = (size_t)(H / 2) * (W / 2), p4 = (size_t)(H / 4) * (W / 4),
                  p8 = (size_t)(H / 8) * (W / 8);
     size_t o = L.total;
@@ -534,8 +536,22 @@ static int refine_left(lws_ctx *h, const float *left, int B, int H, int W, const
 }
 
 // models.py:159-162: refinement1_disp(pred3), refinement2(concat), + pred3.  Needs refine_left's result in r_a.
-static int refine_rest(lws_ctx *h, const float *pred3, int B, int H, int W, const WsLayout &L, float *pred4,
-                       hipStream_t st)
+// Deferred full-resolution maps: the fused last-layer + soft-argmin kernel of stage s (s = 1, 2) leaves the
+// low-resolution disparity low[s]; instead of a k_upsample_add launch on the critical chain, the consumer of
+// pred_out[s] (stage 3's warp kernel for s = 1, the refinement's first block for s = 2) evaluates
+// upsample(low[s]) + pred_out[s-1] on demand (DeferredMap, lws_device_math.h: the same operations, bit for bit) and
+// writes the map out as a by-product, since it is an output of the path.
+struct DeferState {
+    bool allow_last = false;                 // the caller will consume pred_out[2] through refine_rest
+    bool def[3] = {false, false, false};
+    const float *low[3] = {nullptr, nullptr, nullptr};
+    int lh[3] = {0, 0, 0}, lw[3] = {0, 0, 0};
+};
+
+static bool refine_can_defer(const lws_ctx *h);
+
+static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLayout &L, float *pred4,
+                       hipStream_t st, const DeferState *ds = nullptr, const float *pred2 = nullptr)
 {
     const Net2d &n = h->net2d;
     float *ra = h->ws + L.r_a, *rb = h->ws + L.r_b, *rc_ = h->ws + L.r_c;
@@ -546,7 +562,13 @@ static int refine_rest(lws_ctx *h, const float *pred3, int B, int H, int W, cons
     }();
     if (fuse_first && ref_first_dws_can_fuse(n.r1[1][0], 1)) {
         // refinement1_disp: the 1 -> 32 convolution is recomputed inside the first block's staging (one launch less)
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[1][0], pred3, n.r1_first[1], rc_, B, H, W, st));
+        if (ds != nullptr && ds->def[2]) {
+            // pred3 = upsample(low[2]) + pred2 was not materialised: this kernel evaluates it and writes it out
+            LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[1][0], pred2, n.r1_first[1], rc_, B, H, W, st, ds->low[2],
+                                                        ds->lh[2], ds->lw[2], pred3));
+        } else {
+            LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[1][0], pred3, n.r1_first[1], rc_, B, H, W, st));
+        }
     } else {
         LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(pred3, 1, n.r1_first[1], rb, B, H, W, st));
         LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][0], rb, rc_, B, H, W, st));
@@ -564,9 +586,18 @@ static int refine_rest(lws_ctx *h, const float *pred3, int B, int H, int W, cons
 }
 #undef LWS_RF
 
+static bool refine_can_defer(const lws_ctx *h)
+{
+    static const bool fuse_first = [] {
+        const char *e = getenv("LWS_FUSE_FIRST");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return fuse_first && h->have_2d && ref_first_dws_can_fuse(h->net2d.r1[1][0], 1);
+}
+
 static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *const featsR[3], int B, int H, int W,
                        float *const pred_out[3], const WsLayout &L, hipStream_t st, hipEvent_t *feat_ready = nullptr,
-                       const std::function<int()> &after_stage1_stack = nullptr);
+                       const std::function<int()> &after_stage1_stack = nullptr, DeferState *ds = nullptr);
 
 }  // namespace lws
 
@@ -577,19 +608,31 @@ namespace lws {
 // feat_ready (optional): events after which the stage-2 / stage-3 feature maps are complete (feat_ready[1], [2])
 static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *const featsR[3], int B, int H, int W,
                        float *const pred_out[3], const WsLayout &L, hipStream_t st, hipEvent_t *feat_ready,
-                       const std::function<int()> &after_stage1_stack)
+                       const std::function<int()> &after_stage1_stack, DeferState *ds)
 {
     int rc;
-    float *act_a = h->ws + L.act_a, *act_b = h->ws + L.act_b, *raw = h->ws + L.cost_raw, *cost = h->ws + L.cost_out,
-          *low = h->ws + L.low;
+    float *act_a = h->ws + L.act_a, *act_b = h->ws + L.act_b, *raw = h->ws + L.cost_raw, *cost = h->ws + L.cost_out;
+    static const bool defer_up = [] {
+        const char *e = getenv("LWS_DEFER_UPSAMPLE");
+        return e ? atoi(e) != 0 : true;
+    }();
+    DeferState local;
+    if (ds == nullptr) ds = &local;
     static const int feat_c[3] = {16, 16, 8};   // feature_extraction outputs, submodules.py:101,104,186
     for (int s = 0; s < 3; ++s) {
         int D, hh, ww;
         stage_dims(h, s, H, W, D, hh, ww);
+        float *low = h->ws + L.low[s];
         if (s > 0 && feat_ready != nullptr) LWS_HIP(hipStreamWaitEvent(st, feat_ready[s], 0));
         if (s == 0) {
             ProfScope p(h, LWS_KC_VOLUME_SHIFT, st);
             rc = launch_volume_l1_shift(featsL[0], featsR[0], raw, B, feat_c[0], hh, ww, D, st, h->cfg.feature_fp16 != 0);   // :131
+        } else if (ds->def[s - 1]) {
+            // pred_out[s-1] is deferred: read it as upsample(low[s-1]) + pred_out[s-2] and write it out
+            ProfScope p(h, LWS_KC_VOLUME_WARP, st);
+            rc = launch_volume_l1_warp(featsL[s], featsR[s], pred_out[s - 2], raw, nullptr, B, feat_c[s], hh, ww, H, W,
+                                       h->cfg.maxdisplist[s], st, h->cfg.feature_fp16 != 0, ds->low[s - 1], ds->lh[s - 1],
+                                       ds->lw[s - 1], pred_out[s - 1]);
         } else {
             ProfScope p(h, LWS_KC_VOLUME_WARP, st);
             rc = launch_volume_l1_warp(featsL[s], featsR[s], pred_out[s - 1], raw, nullptr, B, feat_c[s], hh, ww, H, W,
@@ -610,6 +653,16 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
             rc = launch_softargmin_upsample(cost, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], nullptr, B, D, hh, ww,
                                             H, W, start, st);
             if (rc) return rc;
+            continue;
+        }
+        // stage 2's map is consumed by stage 3's warp at exactly half resolution; stage 3's by the refinement
+        // (measured r01: two launches fewer are worth +0.5 % at batch 1; at batch 8 the heavier consumers cost 1.2 %, so
+        // large batches keep the separate k_upsample_add launches)
+        if (defer_up && B <= 2 && (s == 1 || (s == 2 && ds->allow_last))) {
+            ds->def[s] = true;
+            ds->low[s] = low;
+            ds->lh[s] = hh;
+            ds->lw[s] = ww;
             continue;
         }
         {
@@ -931,7 +984,7 @@ int lws_refine(lws_handle h, const float *left, const float *pred3, int B, int H
     if (rc) return rc;
     rc = refine_left(h, left, B, H, W, L, (hipStream_t)stream);
     if (rc) return rc;
-    return refine_rest(h, pred3, B, H, W, L, pred4, (hipStream_t)stream);
+    return refine_rest(h, const_cast<float *>(pred3), B, H, W, L, pred4, (hipStream_t)stream);   // not written without a DeferState
 }
 
 int lws_forward(lws_handle h, const float *left, const float *right, int B, int H, int W, float *const pred_out[4],
@@ -990,10 +1043,12 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
         LWS_HIP(hipStreamWaitEvent(h->side, h->ev_feat[0], 0));
         return feature_tail(h, 2 * B, H, W, L, f8, f4, f2, h->side, h->ev_feat, 2);
     };
-    rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st, h->ev_feat, launch_tail);     // :115-156
+    DeferState ds;
+    ds.allow_last = refine_can_defer(h);
+    rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st, h->ev_feat, launch_tail, &ds);     // :115-156
     if (rc) return rc;
     LWS_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
-    return refine_rest(h, pred_out[2], B, H, W, L, pred_out[3], st);                    // :159-162
+    return refine_rest(h, pred_out[2], B, H, W, L, pred_out[3], st, &ds, pred_out[1]);       // :159-162
 }
 
 }  // extern "C"

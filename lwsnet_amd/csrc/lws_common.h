@@ -170,7 +170,8 @@ namespace lws {
 int launch_volume_l1_shift(const float *L, const float *R, float *cost, int B, int C, int h, int w, int D,
                            hipStream_t st, bool q16 = false);
 int launch_volume_l1_warp(const float *L, const float *R, const float *prev, float *cost, float *wflow_out,
-                          int B, int C, int h, int w, int H, int W, int m, hipStream_t st, bool q16 = false);
+                          int B, int C, int h, int w, int H, int W, int m, hipStream_t st, bool q16 = false,
+                          const float *plow = nullptr, int ph = 0, int pw = 0, float *pmat = nullptr);   // deferred prev map
 int launch_softargmin(const float *cost, float *low, int B, int D, int h, int w, float start, hipStream_t st);
 int launch_upsample_add(const float *low, const float *prev, float *out, int B, int h, int w, int H, int W,
                         hipStream_t st);
@@ -196,7 +197,7 @@ int launch_ref_first(const float *in, int cin, const float *w, float *out, int B
 int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, int W, hipStream_t st);
 bool ref_first_dws_can_fuse(const RefDws &l, int cin);
 int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst, float *out, int B, int H, int W,
-                         hipStream_t st);
+                         hipStream_t st, const float *plow = nullptr, int ph = 0, int pw = 0, float *pmat = nullptr);
 int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, float *out, int B, int H, int W,
                       hipStream_t st);
 int launch_ref_last(const float *in, const float *w, const float *pred3, float *out, int B, int H, int W, hipStream_t st);

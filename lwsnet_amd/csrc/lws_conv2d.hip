@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "lws_common.h"
+#include "lws_device_math.h"
 
 namespace lws {
 
@@ -476,8 +477,12 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
                                                  const float *__restrict__ bn_s,
                                                  const float *__restrict__ bn_t, const float *__restrict__ dw,   // [tap][32]
                                                  const float4 *__restrict__ pwpk,                              // [q][mt][lane]
-                                                 float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt)
+                                                 float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt,
+                                                 const float *__restrict__ plow, int ph, int pw, float *__restrict__ pmat)
 {
+    // (FIRST only) plow != nullptr: the disparity map has not been materialised -- it is evaluated on demand as
+    // upsample(plow [ph,pw]) + in (DeferredMap) and this workgroup writes its own tile pixels of it to pmat (the
+    // phase-grid tiles of all workgroups partition the image, so the map is written exactly once)
     __shared__ float4 sA[8 * DWS_SA];
     __shared__ float4 sB[8 * DWS_SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -494,7 +499,8 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
     bool okv[SITER];
     if (FIRST) {
         float *sImg = reinterpret_cast<float *>(sB);
-        const float *img = in + (int64_t)t.b * H * W;
+        const DeferredMap dm{plow != nullptr ? plow + (int64_t)t.b * ph * pw : nullptr, in + (int64_t)t.b * H * W, ph, pw,
+                             (float)H, 1.0f / (float)(ph > 0 ? ph : 1)};
         const int gy0 = t.Y0 - DWS_FD - 1, gx0 = t.X0 - DWS_FD - 1;
         float iv[4];
         bool iok[4];
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
             const int ry = r / DWS_FC, rx = r - ry * DWS_FC;
             const int gy = gy0 + ry, gx = gx0 + rx;
             iok[k] = r < DWS_FR * DWS_FC && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            iv[k] = img[iok[k] ? gy * W + gx : 0];
+            iv[k] = deferred_at(dm, iok[k] ? gy : 0, iok[k] ? gx : 0, H, W);
         }
         float4 wq[9];
 #pragma unroll
@@ -513,6 +519,12 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
         for (int k = 0; k < 4; ++k)
             if (tid + 256 * k < DWS_FR * DWS_FC) sImg[tid + 256 * k] = iok[k] ? iv[k] : 0.0f;
         __syncthreads();
+        if (pmat != nullptr && tid < RT_Y * RT_X) {
+            const int ty = tid / RT_X, tx = tid - ty * RT_X;
+            const int gy = t.Y0 + ty * DWS_FD, gx = t.X0 + tx * DWS_FD;
+            if (gy < H && gx < W)
+                pmat[(int64_t)t.b * H * W + (int64_t)gy * W + gx] = sImg[((ty + 1) * DWS_FD + 1) * DWS_FC + (tx + 1) * DWS_FD + 1];
+        }
 #pragma unroll
         for (int i = 0; i < SITER; ++i) {
             const int hp = (tid >> 3) + 32 * i;
@@ -845,7 +857,7 @@ int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, i
     dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
     hipLaunchKernelGGL(k_ref_dws<false>, grid, block, 0, st, in, (const float *)nullptr, l.bn_s, l.bn_t, l.dw,
                        reinterpret_cast<const float4 *>(l.pw), out, H, W, l.dil, nbx, nby,
-                       use_wt_stores((size_t)B * H * W * 128));
+                       use_wt_stores((size_t)B * H * W * 128), (const float *)nullptr, 0, 0, (float *)nullptr);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -854,7 +866,7 @@ int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, i
 bool ref_first_dws_can_fuse(const RefDws &l, int cin) { return cin == 1 && l.dil == DWS_FD; }
 
 int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst, float *out, int B, int H, int W,
-                         hipStream_t st)
+                         hipStream_t st, const float *plow, int ph, int pw, float *pmat)
 {
     if (!ref_first_dws_can_fuse(l, 1)) {
         set_error("ref_first_dws: dilation %d unsupported", l.dil);
@@ -864,7 +876,7 @@ int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst,
     dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
     hipLaunchKernelGGL(k_ref_dws<true>, grid, block, 0, st, img, wfirst, l.bn_s, l.bn_t, l.dw,
                        reinterpret_cast<const float4 *>(l.pw), out, H, W, l.dil, nbx, nby,
-                       use_wt_stores((size_t)B * H * W * 128));
+                       use_wt_stores((size_t)B * H * W * 128), plow, ph, pw, pmat);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }

@@ -25,6 +25,48 @@ __device__ __forceinline__ float lws_expf(float x)
     return __int_as_float(bits);
 }
 
+// Half-pixel bilinear source index (F.interpolate align_corners=False, align_mode=0).
+__device__ __forceinline__ void src_index(int dst, float ratio, int in, int &i0, int &i1, float &l0, float &l1)
+{
+    float s = ratio * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0.0f) s = 0.0f;
+    int a = (int)s;
+    if (a > in - 1) a = in - 1;
+    i0 = a;
+    i1 = (a < in - 1) ? a + 1 : a;
+    l1 = s - (float)a;
+    l0 = 1.0f - l1;
+}
+
+// A "deferred" full-resolution disparity map: pred(Y,X) = upsample(low * H / h)(Y,X) + prev(Y,X) evaluated on demand
+// with exactly the operations of k_upsample_add (models.py:145-148,153-156), so a consumer can read the map before
+// the kernel that materialises it has run.  low == nullptr: the map is materialised, read prev directly.
+struct DeferredMap {
+    const float *low;     // [h,w] of this image, or nullptr
+    const float *prev;    // [H,W] of this image (the previous stage's map; the materialised map if low == nullptr)
+    int h, w;
+    float mul_a, mul_b;   // (float)H, 1/(float)h
+};
+
+__device__ __forceinline__ float deferred_at(const DeferredMap &m, int y, int x, int H, int W)
+{
+    const float pv = m.prev[(int64_t)y * W + x];
+    if (m.low == nullptr) return pv;
+    const float rh = (float)m.h / (float)H, rw = (float)m.w / (float)W;
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    src_index(y, rh, m.h, y0, y1, hy0, hy1);
+    src_index(x, rw, m.w, x0, x1, wx0, wx1);
+    const float p00 = (m.low[y0 * m.w + x0] * m.mul_a) * m.mul_b;
+    const float p01 = (m.low[y0 * m.w + x1] * m.mul_a) * m.mul_b;
+    const float p10 = (m.low[y1 * m.w + x0] * m.mul_a) * m.mul_b;
+    const float p11 = (m.low[y1 * m.w + x1] * m.mul_a) * m.mul_b;
+    const float top = p00 * wx0 + p01 * wx1;
+    const float bot = p10 * wx0 + p11 * wx1;
+    float v = hy0 * top + hy1 * bot;
+    return v + pv;
+}
+
 // sum_k softmax_k(-c) * (start + k) over D values c[k*stride]: max-subtracted, S summed ascending,
 // p_k = e_k / S (IEEE division), expectation summed ascending.  e_k is recomputed in the third
 // pass instead of being kept in a D-sized register array (it is a pure function, so identical).

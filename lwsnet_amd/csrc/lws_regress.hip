@@ -61,18 +61,6 @@ int launch_softargmin(const float *cost, float *low, int B, int D, int h, int w,
     return LWS_OK;
 }
 
-__device__ __forceinline__ void src_index_up(int dst, float ratio, int in, int &i0, int &i1, float &l0, float &l1)
-{
-    float s = ratio * ((float)dst + 0.5f) - 0.5f;
-    if (s < 0.0f) s = 0.0f;
-    int a = (int)s;
-    if (a > in - 1) a = in - 1;
-    i0 = a;
-    i1 = (a < in - 1) ? a + 1 : a;
-    l1 = s - (float)a;
-    l0 = 1.0f - l1;
-}
-
 // One thread per full-resolution pixel; the low-resolution map is tiny and L2-resident.
 __global__ __launch_bounds__(256) void k_upsample_add(const float *__restrict__ low,
                                                       const float *__restrict__ prev,
@@ -86,8 +74,8 @@ __global__ __launch_bounds__(256) void k_upsample_add(const float *__restrict__ 
     const float rh = (float)h / (float)H, rw = (float)w / (float)W;
     int y0, y1, x0, x1;
     float hy0, hy1, wx0, wx1;
-    src_index_up(y, rh, h, y0, y1, hy0, hy1);
-    src_index_up(x, rw, w, x0, x1, wx0, wx1);
+    src_index(y, rh, h, y0, y1, hy0, hy1);
+    src_index(x, rw, w, x0, x1, wx0, wx1);
     const float *p = low + (int64_t)b * h * w;
     float p00 = (p[(int64_t)y0 * w + x0] * mul_a) * mul_b;
     float p01 = (p[(int64_t)y0 * w + x1] * mul_a) * mul_b;
@@ -172,8 +160,8 @@ __global__ __launch_bounds__(256) void k_softargmin_upsample(const float *__rest
         if (y >= H || x >= W) continue;
         int y0, y1, x0, x1;
         float hy0, hy1, wx0, wx1;
-        src_index_up(y, rh, h, y0, y1, hy0, hy1);
-        src_index_up(x, rw, w, x0, x1, wx0, wx1);
+        src_index(y, rh, h, y0, y1, hy0, hy1);
+        src_index(x, rw, w, x0, x1, wx0, wx1);
         const float *p = sLow + (1 - ly0) * SU_HX + (1 - lx0);      // low-res (y,x) -> sLow[(y-ly0+1)*HX + x-lx0+1]
         float p00 = (p[y0 * SU_HX + x0] * mul_a) * mul_b;
         float p01 = (p[y0 * SU_HX + x1] * mul_a) * mul_b;

@@ -6,6 +6,7 @@
 #include <hip/hip_fp16.h>
 
 #include "lws_common.h"
+#include "lws_device_math.h"
 
 namespace lws {
 
@@ -91,21 +92,6 @@ int launch_volume_l1_shift(const float *L, const float *R, float *cost, int B, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// Half-pixel bilinear source index (F.interpolate align_corners=False, align_mode=0).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void src_index(int dst, float ratio, int in, int &i0, int &i1, float &l0, float &l1)
-{
-    float s = ratio * ((float)dst + 0.5f) - 0.5f;
-    if (s < 0.0f) s = 0.0f;
-    int a = (int)s;
-    if (a > in - 1) a = in - 1;
-    i0 = a;
-    i1 = (a < in - 1) ? a + 1 : a;
-    l1 = s - (float)a;
-    l0 = 1.0f - l1;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Stage-2/3 residual volume.  One thread = one (pixel, hypothesis k); grid.y = k so that a
 // wave reads 64 consecutive pixels of one row.  The 9x expansion of L, R and disp the
 // reference materialises (models.py:85-99) is pure index arithmetic here.  The previous
@@ -120,8 +106,14 @@ __global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict_
                                                         const float *__restrict__ prev,
                                                         float *__restrict__ cost,
                                                         float *__restrict__ wflow_out, int h, int w,
-                                                        int H, int W, int m, float mul_a, float mul_b)
+                                                        int H, int W, int m, float mul_a, float mul_b,
+                                                        const float *__restrict__ plow, int ph, int pw,
+                                                        float *__restrict__ pmat)
 {
+    // plow != nullptr: the previous stage's full-resolution map has not been materialised (no k_upsample_add launch):
+    // it is evaluated on demand as upsample(plow [ph,pw]) + prev (prev = the map of the stage before it), see
+    // DeferredMap.  With H == 2h, W == 2w the four taps of pixel (y,x) are exactly the 2 x 2 block (2y..2y+1,
+    // 2x..2x+1) of that map, so the k == 0 threads also write it out (pmat) -- the map is an output of the path.
     const int pix = blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y, b = blockIdx.z;
     const int64_t plane = (int64_t)h * w;
@@ -137,9 +129,19 @@ __global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict_
         float hy0, hy1, wx0, wx1;
         src_index(y, rh, H, y0, y1, hy0, hy1);
         src_index(x, rw, W, x0, x1, wx0, wx1);
-        const float *p = prev + (int64_t)b * H * W;
-        float top = p[(int64_t)y0 * W + x0] * wx0 + p[(int64_t)y0 * W + x1] * wx1;
-        float bot = p[(int64_t)y1 * W + x0] * wx0 + p[(int64_t)y1 * W + x1] * wx1;
+        const DeferredMap dm{plow != nullptr ? plow + (int64_t)b * ph * pw : nullptr, prev + (int64_t)b * H * W, ph, pw,
+                             (float)H, 1.0f / (float)(ph > 0 ? ph : 1)};
+        const float q00 = deferred_at(dm, y0, x0, H, W), q01 = deferred_at(dm, y0, x1, H, W);
+        const float q10 = deferred_at(dm, y1, x0, H, W), q11 = deferred_at(dm, y1, x1, H, W);
+        if (pmat != nullptr && k == 0) {
+            float *pm = pmat + (int64_t)b * H * W;
+            pm[(int64_t)y0 * W + x0] = q00;
+            pm[(int64_t)y0 * W + x1] = q01;
+            pm[(int64_t)y1 * W + x0] = q10;
+            pm[(int64_t)y1 * W + x1] = q11;
+        }
+        float top = q00 * wx0 + q01 * wx1;
+        float bot = q10 * wx0 + q11 * wx1;
         wf = hy0 * top + hy1 * bot;
         wf = wf * mul_a;
         wf = wf * mul_b;
@@ -209,17 +211,22 @@ __global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict_
 }
 
 int launch_volume_l1_warp(const float *L, const float *R, const float *prev, float *cost, float *wflow_out,
-                          int B, int C, int h, int w, int H, int W, int m, hipStream_t st, bool q16)
+                          int B, int C, int h, int w, int H, int W, int m, hipStream_t st, bool q16, const float *plow,
+                          int ph, int pw, float *pmat)
 {
+    if (pmat != nullptr && (plow == nullptr || H != 2 * h || W != 2 * w)) {
+        set_error("volume_l1_warp: the deferred map can only be written out at exactly half resolution");
+        return LWS_ERR_INVALID;
+    }
     dim3 grid(cdiv(h * w, 256), 2 * m - 1, B), block(256);
     const float mul_a = (float)h, mul_b = 1.0f / (float)H;
 #define LWS_VW(CC)                                                                                                   \
     if (q16)                                                                                                          \
         hipLaunchKernelGGL((k_volume_l1_warp<CC, true>), grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m,  \
-                           mul_a, mul_b);                                                                             \
+                           mul_a, mul_b, plow, ph, pw, pmat);                                                                             \
     else                                                                                                              \
         hipLaunchKernelGGL((k_volume_l1_warp<CC, false>), grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m, \
-                           mul_a, mul_b)
+                           mul_a, mul_b, plow, ph, pw, pmat)
     switch (C) {
         case 8: LWS_VW(8); break;
         case 16: LWS_VW(16); break;

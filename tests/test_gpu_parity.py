@@ -204,6 +204,17 @@ def test_forward_bitexact_vs_c_oracle(dev, model):
         assert_bits(pred[s], want[s], f"forward stage {s + 1}")
 
 
+def test_forward_batch_paths_agree(dev, model):
+    """Batches of 1-2 pairs skip the k_upsample_add launches (the consumers evaluate and write the stage-2/3 maps,
+    DeferredMap); larger batches launch them.  Both orchestrations must give the same bits for every stage map."""
+    left, right = make_batch(3, 64, 256, 11)
+    p3 = model(left, right)
+    for i in range(3):
+        p1 = model(left[i:i + 1], right[i:i + 1])
+        for s in range(4):
+            assert torch.equal(p1[s], p3[s][i:i + 1]), f"pair {i} stage {s + 1}"
+
+
 def test_forward_matches_literal_oracle(dev, model):
     """LWSNet.forward end to end (all kernels native) vs the literal oracle's golden stage maps."""
     g = golden("e2e_64x256.npz")
