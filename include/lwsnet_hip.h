@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LWS_ABI_VERSION 2
+#define LWS_ABI_VERSION 3
 
 typedef enum {
     LWS_OK = 0,
