@@ -363,3 +363,34 @@ def test_config5_maxdisp256(dev, hip_lib):
     want = C.forward(l2, r2, sd, (32, 5, 5))
     for s in range(4):
         assert_bits(got[s], want[s], f"maxdisplist [32,5,5], stage {s + 1}")
+
+
+# ------------------------------------------------------------------ measurement hooks
+def test_profiler_counts_and_sampling(dev, model, hip_lib):
+    """lws_profile_enable/_sample/_read (include/lwsnet_hip.h): launch counts per kernel class for one forward, and
+    every-n-th-call sampling used by bench.py's roofline leg."""
+    import ctypes
+    from lwsnet_amd import _lib
+    left, right = make_batch(1, 64, 256, 5)
+    tot = (ctypes.c_double * _lib.LWS_KC_COUNT)()
+    cnt = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
+    names = [hip_lib.lws_kernel_class_name(k).decode() for k in range(_lib.LWS_KC_COUNT)]
+    _lib.check(hip_lib.lws_profile_enable(model._h, -1))
+    model(left, right)
+    torch.cuda.synchronize()
+    _lib.check(hip_lib.lws_profile_read(model._h, tot, cnt))
+    got = dict(zip(names, list(cnt)))
+    assert got["conv3d_mid16"] == 4 and got["conv3d_mid8"] == 8 and got["conv3d_first"] == 3 and got["conv3d_last"] == 3
+    assert got["volume_l1_shift"] == 1 and got["volume_l1_warp"] == 2 and got["ref_conv64"] == 1 and got["ref_dws"] == 12
+    assert all(t >= 0.0 for t in tot) and tot[names.index("conv3d_mid16")] > 0.0
+    # sampling: 6 calls, every 3rd recorded -> 2 forwards' worth of mid16 launches
+    _lib.check(hip_lib.lws_profile_enable(model._h, 1 << names.index("conv3d_mid16")))
+    _lib.check(hip_lib.lws_profile_sample(model._h, 3))
+    for _ in range(6):
+        model(left, right)
+    torch.cuda.synchronize()
+    _lib.check(hip_lib.lws_profile_read(model._h, tot, cnt))
+    assert cnt[names.index("conv3d_mid16")] == 8 and sum(cnt) == 8
+    _lib.check(hip_lib.lws_profile_enable(model._h, 0))
+    with pytest.raises(Exception):
+        _lib.check(hip_lib.lws_profile_sample(model._h, 0))
