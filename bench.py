@@ -161,6 +161,17 @@ def main():
     torch.cuda.synchronize()
     _lib.check(lib.lws_profile_read(model._h, tot, cnt), "lws_profile_read")
     _lib.check(lib.lws_profile_enable(model._h, 0), "lws_profile_enable")
+    # untimed latency pass: one forward at a time, host call -> result complete (SURVEY.md section 8d asks for the
+    # spread as well as the mean; the throughput above keeps the stream full, this does not)
+    lat = []
+    for _ in range(50):
+        t1 = time.perf_counter()
+        models[0](left, right)
+        torch.cuda.synchronize()
+        lat.append(1e3 * (time.perf_counter() - t1))
+    lat.sort()
+    latency = {"p10": round(lat[5], 4), "p50": round(lat[25], 4), "p90": round(lat[45], 4),
+               "what": "ms per isolated forward (host call to stream idle), 50 samples"}
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -236,7 +247,7 @@ def main():
                                 f"batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[{args.maxdisp0},5,5], all 4 stages"),
                    "pairs_per_gpu": B, "streams": S, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4" if world > 1 else "single GPU",
                    "weights": "seeded synthetic (seed 7, calibrated BN)"},
-        "roofline": _with_traffic(roof, B), "cpu_baseline": cpu,
+        "roofline": _with_traffic(roof, B), "cpu_baseline": cpu, "latency_ms": latency,
         "hot_path_kernel_ms_per_step": round(hot_ms, 4), "all_kernel_ms_per_step": round(all_ms, 4), "kernels": {k: {a: round(b, 2) for a, b in v.items()} for k, v in kernels.items()},
     }
     print(json.dumps(out), flush=True)
