@@ -184,7 +184,11 @@ template <int CIN, int CM, int COUT, int SA, int DA, int DB, int NW>
 struct PairCfg {
     static constexpr int NT = 64 * NW;
     static constexpr int MR = 8 + 2 * DB, MRp = MR | 1;
-    static constexpr int RH = (MR - 1) * SA + 2 * DA + 1, RWp = RH | 1;
+    static constexpr int RH = (MR - 1) * SA + 2 * DA + 1;
+    // stride-2 layers read every other column: the input rows are stored de-interleaved by column parity (even
+    // columns, then odd columns) so that consecutive lanes hit consecutive LDS banks instead of every second one
+    static constexpr int HALF = (RH + 1) / 2, RWp = (SA == 2 ? 2 * HALF : RH) | 1;
+    __host__ __device__ static constexpr int col(int rx) { return SA == 2 ? (rx & 1) * HALF + (rx >> 1) : rx; }
     static constexpr int WGA_ = (MR * MR + 63) / 64;                                  // waves needed for one pass over A's region
     static constexpr int WGA = WGA_ <= 1 ? 1 : WGA_ <= 2 ? 2 : WGA_ <= 4 ? 4 : WGA_ <= 8 ? 8 : 16;
     static constexpr int GA = NW / WGA, CPA = CM / GA, CPB = COUT / NW;
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv2d_pair(const float *__restrict
             const int it = tid + i * NT;
             const int ci = it / RSZ, r = it - ci * RSZ;
             const int ry = r / RH, rx = r - ry * RH;
-            if (it < Cfg::ITEMS) sIn[(ci * RH + ry) * RWp + rx] = okv[i] ? v[i] : 0.0f;
+            if (it < Cfg::ITEMS) sIn[(ci * RH + ry) * RWp + Cfg::col(rx)] = okv[i] ? v[i] : 0.0f;
         }
     }
     __syncthreads();
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv2d_pair(const float *__restrict
 #pragma unroll 3
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap - kh * 3;
-                const float *pp = sIn + (my * SA + kh * DA) * RWp + mx * SA + kw * DA;
+                const float *pp = sIn + (my * SA + kh * DA) * RWp + Cfg::col(mx * SA + kw * DA);
                 const float *w = wA + (tap * GA + ga) * CIN * CPA;
                 float v[CIN];
 #pragma unroll
