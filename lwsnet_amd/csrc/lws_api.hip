@@ -275,7 +275,7 @@ struct SlabBuilder {
 };
 
 struct Net2dOffsets {
-    struct L { size_t w, wp, s, t; bool bn; };
+    struct L { size_t w, wp, wm, s, t; bool bn; };
     L fe[12];
     size_t r1_first[2];
     struct D { size_t s, t, dw, pw; };
@@ -344,6 +344,12 @@ static void build_net2d(const lws_ctx *h, std::vector<float> &slab, Net2dOffsets
                             wq[(((size_t)tap * G + co / cpg) * d.cin + ci) * cpg + co % cpg] = w[((size_t)co * d.cin + ci) * 9 + tap];
                 o.fe[i].wp = sb.put(wq);
             }
+            o.fe[i].wm = 0;
+            if (i >= 4 && i <= 7) {                   // conv1..conv4: 16 output channels -> MFMA A fragments
+                std::vector<float> wf((size_t)9 * 64 * (d.cin / 4));
+                pack_pair_mfma(w.data(), d.cin, wf.data());
+                o.fe[i].wm = sb.put(wf);
+            }
         }
         o.fe[i].bn = d.bn;
         if (d.bn) {
@@ -394,6 +400,7 @@ static void bind_net2d(lws_ctx *h, const Net2dOffsets &o)
         l.w = h->params + o.fe[i].w;
         l.pair_groups = conv2d_pair_groups(i);
         l.w_pair = l.pair_groups > 0 ? h->params + o.fe[i].wp : nullptr;
+        l.w_mfma = (i >= 4 && i <= 7) ? h->params + o.fe[i].wm : nullptr;
         l.bn_s = d.bn ? h->params + o.fe[i].s : nullptr;
         l.bn_t = d.bn ? h->params + o.fe[i].t : nullptr;
     }

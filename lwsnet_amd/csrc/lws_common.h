@@ -102,6 +102,7 @@ struct Conv2dLayer {
     bool transposed = false, relu = false;
     float *w = nullptr, *bn_s = nullptr, *bn_t = nullptr;
     float *w_pair = nullptr;   // [tap][pair_groups][cin][cout/pair_groups] for k_conv2d_pair (layers 0..7 only)
+    float *w_mfma = nullptr;   // [tap][lane][cin/4] A fragments for k_conv2d_pair_mfma (16-output-channel layers 4..7)
     int pair_groups = 0;
 };
 
@@ -191,6 +192,7 @@ int launch_conv3d_last(const Stage3d &s, const float *act_in, const float *cost_
 int launch_conv2d_nchw(const Conv2dLayer &l, const float *in, const float *res, float *out, int N, int H, int W,
                        hipStream_t st, const float *in2 = nullptr, int n1 = 0);
 int conv2d_pair_groups(int layer);
+void pack_pair_mfma(const float *w, int cin, float *out);
 int launch_conv2d_pair(const Conv2dLayer &a, const Conv2dLayer &b, const float *in, const float *res, float *out, int N,
                        int H, int W, hipStream_t st, const float *in2 = nullptr, int n1 = 0);
 int launch_ref_first(const float *in, int cin, const float *w, float *out, int B, int H, int W, hipStream_t st);

@@ -339,6 +339,176 @@ static int conv2d_pair_launch(const Conv2dLayer &a, const Conv2dLayer &b, const 
     return LWS_OK;
 }
 
+// =============================================================================================
+// The two 16-channel pairs (conv1+conv2 at 1/4, conv3+conv4 at 1/8 resolution: stride-2 3x3 CIN -> 16, then 3x3
+// 16 -> 16) on fp32 MFMA: with 16 output channels a layer is exactly one 16-row MFMA tile, Out^T[cout, pixel] =
+// sum_{tap, cin} W[cout, (tap, cin)] X[(tap, cin), pixel], K = 4 input channels of one tap per instruction, taps outer
+// and channels ascending -- the same fma chain as the VALU kernel, so the results are bit-identical.  The LDS images
+// are the planar ones of k_conv2d_pair (lane (n, g) reads channel 4j+g of pixel n with one ds_read_b32 at
+// lane base + compile-time offset); the 9 x CIN/4 A fragments of a layer (one VGPR each) are loaded up front.
+// 8 waves stage the input region; wave w < 7 owns pixels 16w .. 16w+15 of layer A's 10 x 10 region, waves 0..3 the
+// 8 x 8 output tile (the layers are latency-bound: the short dependent MFMA chains matter, not the idle waves;
+// 16-wave workgroups were no faster at batch 1 and are starved of LDS by the side stream's kernels at batch 8).
+// =============================================================================================
+template <int CIN>
+struct PairMfmaCfg {
+    static constexpr int NT = 512, MR = 10, MRp = 11, RH = 21, HALF = 11, RWp = 23;
+    static constexpr int JA = CIN / 4, JB = 4;                       // K groups per tap of layer A / layer B
+    static constexpr int PIN = RH * RWp, PMID = MR * MRp;            // plane strides
+    static constexpr int ITEMS = CIN * RH * RH, SITER = (ITEMS + NT - 1) / NT;
+    static constexpr int LDS_FLOATS = CIN * PIN + 16 * PMID;
+    __host__ __device__ static constexpr int col(int rx) { return (rx & 1) * HALF + (rx >> 1); }
+};
+
+template <int CIN>
+__global__ __launch_bounds__(512) void k_conv2d_pair_mfma(const float *__restrict__ in, const float *__restrict__ in2, int n1,
+                                                          const float *__restrict__ wA,   // [tap][lane][JA] A fragments
+                                                          const float *__restrict__ sA_, const float *__restrict__ tA_,
+                                                          int reluA,
+                                                          const float *__restrict__ wB,   // [tap][lane][4]
+                                                          const float *__restrict__ sB_, const float *__restrict__ tB_,
+                                                          int reluB, float *__restrict__ out, int H, int W, int HA, int WA)
+{
+    using Cfg = PairMfmaCfg<CIN>;
+    constexpr int NT = Cfg::NT, MR = Cfg::MR, MRp = Cfg::MRp, RH = Cfg::RH, RWp = Cfg::RWp, JA = Cfg::JA, JB = Cfg::JB,
+                  PIN = Cfg::PIN, PMID = Cfg::PMID, SITER = Cfg::SITER, RSZ = RH * RH;
+    extern __shared__ float smem[];
+    float *sIn = smem;                  // [CIN][RH][RWp], columns de-interleaved by parity
+    float *sMid = smem + CIN * PIN;     // [16][MR][MRp]
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int ox0 = blockIdx.x * 8, oy0 = blockIdx.y * 8;
+    const int my0 = oy0 - 1, mx0 = ox0 - 1;
+    const int iy0 = my0 * 2 - 1, ix0 = mx0 * 2 - 1;
+    const int plane = H * W;
+    const float *inb = b < n1 ? in + (int64_t)b * CIN * plane : in2 + (int64_t)(b - n1) * CIN * plane;
+    constexpr int STAMP_ID = CIN == 8 ? 15 : 16;
+    LWS_STAMPK(STAMP_ID, 0);
+    {
+        float v[SITER];
+        bool okv[SITER];
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * NT;
+            const int ci = it / RSZ, r = it - ci * RSZ;
+            const int ry = r / RH, rx = r - ry * RH;
+            const int gy = iy0 + ry, gx = ix0 + rx;
+            okv[i] = it < Cfg::ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            v[i] = inb[okv[i] ? ci * plane + gy * W + gx : 0];
+        }
+        // A fragments and BatchNorm parameters of both layers, for the waves that compute (in flight with the input loads)
+        float fa[9][JA], fb[9][JB];
+        float4 bsA = make_float4(0.f, 0.f, 0.f, 0.f), btA = bsA, bsB = bsA, btB = bsA;
+        if (wave * 16 < MR * MR) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int j = 0; j < JA; ++j) fa[tap][j] = wA[(tap * 64 + lane) * JA + j];
+            bsA = *reinterpret_cast<const float4 *>(sA_ + 4 * g);
+            btA = *reinterpret_cast<const float4 *>(tA_ + 4 * g);
+        }
+        if (wave < 4) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int j = 0; j < JB; ++j) fb[tap][j] = wB[(tap * 64 + lane) * JB + j];
+            if (sB_ != nullptr) {
+                bsB = *reinterpret_cast<const float4 *>(sB_ + 4 * g);
+                btB = *reinterpret_cast<const float4 *>(tB_ + 4 * g);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * NT;
+            const int ci = it / RSZ, r = it - ci * RSZ;
+            const int ry = r / RH, rx = r - ry * RH;
+            if (it < Cfg::ITEMS) sIn[ci * PIN + ry * RWp + Cfg::col(rx)] = okv[i] ? v[i] : 0.0f;
+        }
+        __syncthreads();
+        LWS_STAMPK(STAMP_ID, 1);
+        // layer A: wave = 16-pixel tile of the 10 x 10 region
+        if (wave * 16 < MR * MR) {
+            const int p = wave * 16 + n, pc = p < MR * MR ? p : MR * MR - 1;
+            const int my = pc / MR, mx = pc - my * MR;
+            const float *bp = sIn + g * PIN + (my * 2) * RWp + mx;
+            floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+                for (int j = 0; j < JA; ++j)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[tap][j], bp[(4 * j) * PIN + kh * RWp + Cfg::col(kw)], acc, 0, 0, 0);
+            }
+            const int ay = my0 + my, ax = mx0 + mx;
+            const bool valid = ay >= 0 && ay < HA && ax >= 0 && ax < WA;
+            if (p < MR * MR) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = 4 * g + e;
+                    float r = fmaf(acc[e], f4c(bsA, e), f4c(btA, e));
+                    if (reluA) r = fmaxf(r, 0.0f);
+                    sMid[co * PMID + my * MRp + mx] = valid ? r : 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+        LWS_STAMPK(STAMP_ID, 2);
+        // layer B: waves 0..3 = the four 16-pixel tiles of the 8 x 8 output tile
+        if (wave < 4) {
+            const int p = wave * 16 + n;
+            const int ty = p >> 3, tx = p & 7;
+            const float *bp = sMid + g * PMID + ty * MRp + tx;
+            floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+                for (int j = 0; j < JB; ++j)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[tap][j], bp[(4 * j) * PMID + kh * MRp + kw], acc, 0, 0, 0);
+            }
+            const int ox = ox0 + tx, oy = oy0 + ty;
+            if (ox < WA && oy < HA) {
+                const int oplane = HA * WA;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = 4 * g + e;
+                    float r = acc[e];
+                    if (sB_ != nullptr) r = fmaf(r, f4c(bsB, e), f4c(btB, e));
+                    if (reluB) r = fmaxf(r, 0.0f);
+                    out[((int64_t)b * 16 + co) * oplane + oy * WA + ox] = r;
+                }
+            }
+        }
+        LWS_STAMPK(STAMP_ID, 3);
+    }
+}
+
+// [cout=16][cin][3][3] -> A fragments [tap][lane][cin/4]: lane (m, g) holds W[m][4j+g][tap] for j = 0..cin/4-1
+void pack_pair_mfma(const float *w, int cin, float *out)
+{
+    const int J = cin / 4;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < J; ++j) {
+                const int m = lane & 15, g = lane >> 4;
+                out[((size_t)tap * 64 + lane) * J + j] = w[((size_t)m * cin + 4 * j + g) * 9 + tap];
+            }
+}
+
+template <int CIN>
+static int conv2d_pair_mfma_launch(const Conv2dLayer &a, const Conv2dLayer &b, const float *in, const float *in2, int n1,
+                                   float *out, int N, int H, int W, int HA, int WA, hipStream_t st)
+{
+    using Cfg = PairMfmaCfg<CIN>;
+    const size_t lds = (size_t)Cfg::LDS_FLOATS * sizeof(float);
+    dim3 grid(cdiv(WA, 8), cdiv(HA, 8), N), block(Cfg::NT);
+    hipLaunchKernelGGL((k_conv2d_pair_mfma<CIN>), grid, block, lds, st, in, in2, n1, a.w_mfma, a.bn_s, a.bn_t, a.relu ? 1 : 0,
+                       b.w_mfma, b.bn_s, b.bn_t, b.relu ? 1 : 0, out, H, W, HA, WA);
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
 // Output-channel groups the pair kernel wants for layer i of the feature extractor (0..7: A, B, A, B, ...); the host
 // packs w_pair as [tap][groups][cin][cout/groups].
 int conv2d_pair_groups(int layer)
@@ -362,6 +532,15 @@ int launch_conv2d_pair(const Conv2dLayer &a, const Conv2dLayer &b, const float *
         n1 = N;
     }
     const int HA = (H + 2 * a.pad - 2 * a.dil - 1) / a.stride + 1, WA = (W + 2 * a.pad - 2 * a.dil - 1) / a.stride + 1;
+    static const bool use_mfma = [] {
+        const char *e = getenv("LWS_PAIR_MFMA");
+        return e ? atoi(e) != 0 : true;
+    }();
+    if (use_mfma && a.cout == 16 && b.cout == 16 && a.stride == 2 && a.dil == 1 && b.dil == 1 && res == nullptr &&
+        a.w_mfma != nullptr && b.w_mfma != nullptr && (a.cin == 8 || a.cin == 16)) {
+        if (a.cin == 8) return conv2d_pair_mfma_launch<8>(a, b, in, in2, n1, out, N, H, W, HA, WA, st);
+        return conv2d_pair_mfma_launch<16>(a, b, in, in2, n1, out, N, H, W, HA, WA, st);
+    }
 #define LWS_C2P(CI, CMID, CO, SA, DA, DB, NW)                                                             \
     if (a.cin == CI && a.cout == CMID && b.cout == CO && a.stride == SA && a.dil == DA && b.dil == DB)    \
         return conv2d_pair_launch<CI, CMID, CO, SA, DA, DB, NW>(a, b, in, in2, n1, res, out, N, H, W, HA, WA, st);
