@@ -827,7 +827,7 @@ int lws_finalize(lws_handle h)
         }
     // build one host slab, then upload
     std::vector<float> slab;
-    struct Off { size_t w, s, t; };
+    struct Off { size_t w, s, t, wm; };
     std::vector<Off> offs[3];
     auto al = [&]() { slab.resize((slab.size() + 63) & ~(size_t)63, 0.0f); };
     for (int i = 0; i < 3; ++i) {
@@ -840,8 +840,18 @@ int lws_finalize(lws_handle h)
             Off o;
             al();
             o.w = slab.size();
+            o.wm = 0;
             if (j == 0) {
                 slab.insert(slab.end(), w.begin(), w.end());                    // [c3][27]
+                al();                                                           // + MFMA A fragments
+                o.wm = slab.size();
+                if (c3 == 8) {
+                    slab.resize(o.wm + 9 * 64);
+                    pack_first8_weights(w.data(), slab.data() + o.wm);
+                } else {
+                    slab.resize(o.wm + (size_t)(c3 / 16) * 7 * 64);
+                    pack_first16_weights(w.data(), c3, slab.data() + o.wm);
+                }
             } else if (j == L - 1) {
                 slab.resize(o.w + (size_t)27 * c3);                             // [27][c3]
                 for (int ci = 0; ci < c3; ++ci)
@@ -877,6 +887,7 @@ int lws_finalize(lws_handle h)
             l.cin = j == 0 ? 1 : c3;
             l.cout = j == L - 1 ? 1 : c3;
             l.w = h->params + offs[i][j].w;
+            l.w_mfma = j == 0 ? h->params + offs[i][j].wm : nullptr;
             l.bn_s = h->params + offs[i][j].s;
             l.bn_t = h->params + offs[i][j].t;
         }

@@ -88,6 +88,7 @@ struct Conv3dLayer {
     float *w = nullptr;      // packed weights (layout depends on the kernel that consumes them)
     float *bn_s = nullptr;   // [cin] scale of THIS layer's BatchNorm (applied to its input)
     float *bn_t = nullptr;   // [cin] shift
+    float *w_mfma = nullptr; // first layer only: MFMA A fragments, [9][64] (c3 = 8, k_conv3d_first8) or [c3/16][7][64]
 };
 
 struct Stage3d {
@@ -212,5 +213,7 @@ int launch_conv3d_last_softargmin(const Stage3d &s, const float *act_in, const f
 // host-side weight packing used by lws_finalize
 size_t packed_mid_weight_floats(int c3);
 void pack_mid_weights(const float *w /*[c3][c3][27]*/, int c3, float *out);
+void pack_first8_weights(const float *w /*[8][27]*/, float *out /*[9][64]*/);
+void pack_first16_weights(const float *w /*[c3][27]*/, int c3, float *out /*[c3/16][7][64]*/);
 
 }  // namespace lws

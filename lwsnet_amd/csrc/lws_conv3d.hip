@@ -48,11 +48,13 @@ __global__ __launch_bounds__(256) void k_conv3d_first(const float *__restrict__ 
     // C3/8 threads per voxel, 8 output channels each: a wave stores whole 32 B / 128 B voxel lines.
     constexpr int G = C3 / 8;
     __shared__ __attribute__((aligned(16))) float sW[27 * C3];
+    LWS_STAMPK(4, 0);
     for (int i = threadIdx.x; i < 27 * C3; i += 256) {
         int tap = i / C3, co = i - tap * C3;
         sW[i] = wgt[co * 27 + tap];
     }
     __syncthreads();
+    LWS_STAMPK(4, 1);
     const float s0 = bn0_s[0], t0 = bn0_t[0];
     const int64_t vol = (int64_t)D * h * w;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -95,11 +97,13 @@ __global__ __launch_bounds__(256) void k_conv3d_first(const float *__restrict__ 
         acc[6] = fmaf(a[tap], w1.z, acc[6]);
         acc[7] = fmaf(a[tap], w1.w, acc[7]);
     }
+    LWS_STAMPK(4, 2);
     float4 *out = reinterpret_cast<float4 *>(act + ((int64_t)b * vol + v) * C3 + grp * 8);
     out[0] = make_float4(bn_relu(acc[0], sa.x, ta.x), bn_relu(acc[1], sa.y, ta.y), bn_relu(acc[2], sa.z, ta.z),
                          bn_relu(acc[3], sa.w, ta.w));
     out[1] = make_float4(bn_relu(acc[4], sb.x, tb.x), bn_relu(acc[5], sb.y, tb.y), bn_relu(acc[6], sb.z, tb.z),
                          bn_relu(acc[7], sb.w, tb.w));
+    LWS_STAMPK(4, 3);
 }
 
 // =============================================================================================
@@ -499,6 +503,207 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
 }
 
 // =============================================================================================
+// First layer, C3 == 8 (stages 2 and 3), on fp32 MFMA: k_conv3d_mid8's scheme with one input channel.  Rows =
+// (x parity, cout), columns = voxel pairs, K = the four x positions t = 0..3 both parities read, so each (kd,kh) is ONE
+// MFMA whose A operand is W[cout][kd][kh][t - xpar] (zero outside 0..2) and whose B operand is one ds_read_b32 of the
+// BN0+ReLU'd cost halo tile: 9 MFMAs per row of 32 voxels, taps ascending -- the same chain as k_conv3d_first, which
+// spends its time re-reading broadcast weights from LDS (54 ds_read_b128 per thread: LDS-issue-bound).
+// =============================================================================================
+template <int TD, int TY>
+__global__ __launch_bounds__(256) void k_conv3d_first8(const float *__restrict__ cost,    // [B,D,h,w]
+                                                       const float *__restrict__ wpk,     // [9][64] A fragments
+                                                       const float *__restrict__ bn0_s, const float *__restrict__ bn0_t,
+                                                       const float *__restrict__ bn_s,    // next layer BN [8]
+                                                       const float *__restrict__ bn_t, float *__restrict__ out, int D,
+                                                       int h, int w, int tiles_x, int tiles_y)
+{
+    constexpr int RW = TD * TY / 4, HD = TD + 2, HY = TY + 2, HX = 34, NVOX = HD * HY * HX, SITER = (NVOX + 255) / 256;
+    static_assert(TD * TY % 4 == 0, "rows must split over 4 waves");
+    __shared__ float lds[NVOX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x;
+    tile /= tiles_x;
+    const int ty = tile % tiles_y;
+    const int td = tile / tiles_y;
+    const int b = blockIdx.y;
+    const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
+    const float *cb = cost + (int64_t)b * D * h * w;
+    float c[SITER];
+    bool okv[SITER];
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int v = tid + i * 256;
+        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        okv[i] = v < NVOX && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        c[i] = cb[okv[i] ? ((int64_t)gd * h + gy) * w + gx : 0];
+    }
+    const float s0 = bn0_s[0], t0 = bn0_t[0];
+    const int xpar = g >> 1, cbo = 4 * (g & 1);
+    const float4 es = *reinterpret_cast<const float4 *>(bn_s + cbo);
+    const float4 et = *reinterpret_cast<const float4 *>(bn_t + cbo);
+    float wa[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wa[k] = wpk[k * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int v = tid + i * 256;
+        if (v < NVOX) lds[v] = okv[i] ? bn_relu(c[i], s0, t0) : 0.0f;
+    }
+    __syncthreads();
+    floatx4 acc[RW];
+    int rbase[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        acc[r] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        const int row = wave * RW + r;
+        rbase[r] = ((row / TY) * HY + row % TY) * HX + 2 * n + g;
+    }
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[kd * 3 + kh], lds[rbase[r] + (kd * HY + kh) * HX], acc[r], 0, 0, 0);
+    float *outb = out + (int64_t)b * D * h * w * 8;
+    const int gx = x0 + 2 * n + xpar;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = wave * RW + r;
+        const int gd = d0 + row / TY, gy = y0 + row % TY;
+        if (gd < D && gy < h && gx < w) {
+            float4 v;
+            v.x = bn_relu(acc[r][0], es.x, et.x);
+            v.y = bn_relu(acc[r][1], es.y, et.y);
+            v.z = bn_relu(acc[r][2], es.z, et.z);
+            v.w = bn_relu(acc[r][3], es.w, et.w);
+            *reinterpret_cast<float4 *>(outb + (((int64_t)gd * h + gy) * w + gx) * 8 + cbo) = v;
+        }
+    }
+}
+
+// =============================================================================================
+// First layer, C3 a multiple of 16 (stage 1), on fp32 MFMA: rows = 16 output channels per tile, columns = 16 voxels
+// along x, K = 4 consecutive taps per instruction (27 taps + one zero tap = 7 MFMAs per output-channel tile).  Lane
+// (n, g) of MFMA j supplies tap 4j+g of voxel n: one ds_read_b32 at a per-lane offset into the BN0+ReLU'd cost halo
+// tile, shared by the C3/16 output-channel tiles.  Taps ascending: the same chain as k_conv3d_first.
+// =============================================================================================
+template <int C3, int TD, int TY>
+__global__ __launch_bounds__(256) void k_conv3d_first16(const float *__restrict__ cost,    // [B,D,h,w]
+                                                        const float *__restrict__ wpk,     // [C3/16][7][64] A fragments
+                                                        const float *__restrict__ bn0_s, const float *__restrict__ bn0_t,
+                                                        const float *__restrict__ bn_s,    // next layer BN [C3]
+                                                        const float *__restrict__ bn_t, float *__restrict__ out, int D,
+                                                        int h, int w, int tiles_x, int tiles_y)
+{
+    constexpr int MT = C3 / 16, RW = TD * TY / 4, HD = TD + 2, HY = TY + 2, HX = 18, NVOX = HD * HY * HX,
+                  SITER = (NVOX + 255) / 256;
+    static_assert(TD * TY % 4 == 0 && C3 % 16 == 0, "bad first16 geometry");
+    __shared__ float lds[NVOX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x;
+    tile /= tiles_x;
+    const int ty = tile % tiles_y;
+    const int td = tile / tiles_y;
+    const int b = blockIdx.y;
+    const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
+    const float *cb = cost + (int64_t)b * D * h * w;
+    float c[SITER];
+    bool okv[SITER];
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int v = tid + i * 256;
+        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        okv[i] = v < NVOX && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        c[i] = cb[okv[i] ? ((int64_t)gd * h + gy) * w + gx : 0];
+    }
+    const float s0 = bn0_s[0], t0 = bn0_t[0];
+    float4 es[MT], et[MT];
+    float wa[MT][7];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        es[mt] = *reinterpret_cast<const float4 *>(bn_s + mt * 16 + 4 * g);
+        et[mt] = *reinterpret_cast<const float4 *>(bn_t + mt * 16 + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) wa[mt][j] = wpk[(mt * 7 + j) * 64 + lane];
+    }
+    // halo offset of tap 4j+g (tap 27 does not exist: its weight is zero, any in-tile address will do)
+    int toff[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int tap = 4 * j + g < 27 ? 4 * j + g : 26;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        toff[j] = (kd * HY + kh) * HX + kw + n;
+    }
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int v = tid + i * 256;
+        if (v < NVOX) lds[v] = okv[i] ? bn_relu(c[i], s0, t0) : 0.0f;
+    }
+    __syncthreads();
+    floatx4 acc[RW][MT];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int row = wave * RW + r;
+            const float bv = lds[((row / TY) * HY + row % TY) * HX + toff[j]];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][j], bv, acc[r][mt], 0, 0, 0);
+        }
+    float *outb = out + (int64_t)b * D * h * w * C3;
+    const int gx = x0 + n;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = wave * RW + r;
+        const int gd = d0 + row / TY, gy = y0 + row % TY;
+        if (gd < D && gy < h && gx < w) {
+            float *o = outb + (((int64_t)gd * h + gy) * w + gx) * C3;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float4 v;
+                v.x = bn_relu(acc[r][mt][0], es[mt].x, et[mt].x);
+                v.y = bn_relu(acc[r][mt][1], es[mt].y, et[mt].y);
+                v.z = bn_relu(acc[r][mt][2], es[mt].z, et[mt].z);
+                v.w = bn_relu(acc[r][mt][3], es[mt].w, et[mt].w);
+                *reinterpret_cast<float4 *>(o + mt * 16 + 4 * g) = v;
+            }
+        }
+    }
+}
+
+// [c3][27] -> A fragments [c3/16][7][lane]: lane (m, g) of MFMA j holds W[16 mt + m][tap = 4j + g] (0 for tap 27)
+void pack_first16_weights(const float *w, int c3, float *out)
+{
+    for (int mt = 0; mt < c3 / 16; ++mt)
+        for (int j = 0; j < 7; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = lane & 15, tap = 4 * j + (lane >> 4);
+                out[(mt * 7 + j) * 64 + lane] = tap < 27 ? w[(16 * mt + m) * 27 + tap] : 0.0f;
+            }
+}
+
+// [8][27] -> A fragments [kd*3+kh][lane]: lane (m, t): row m = 8*xpar + cout, W[cout][kd][kh][t - xpar] or 0
+void pack_first8_weights(const float *w, float *out)
+{
+    for (int kdh = 0; kdh < 9; ++kdh)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int m = lane & 15, t = lane >> 4, xpar = m >> 3, cout = m & 7, kw = t - xpar;
+            out[kdh * 64 + lane] = (kw >= 0 && kw <= 2) ? w[cout * 27 + kdh * 3 + kw] : 0.0f;
+        }
+}
+
+// =============================================================================================
 // Last layer: act [B,D,h,w,C3] -> cost_out [B,D,h,w] = conv(act) + cost_in   (models.py:137), optionally
 // followed in the same kernel by the soft-argmin over D (models.py:142,151-152,167-179) when the tile spans
 // the whole disparity axis (stages 2/3: D = 9).
@@ -650,6 +855,32 @@ static void first_launch(const Stage3d &s, const float *cost, float *act, int B,
 int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int B, int D, int h, int w,
                         hipStream_t st)
 {
+    static const bool first_mfma = [] {
+        const char *e = getenv("LWS_FIRST_MFMA");
+        return e ? atoi(e) != 0 : true;
+    }();
+    if (s.c3 == 8 && first_mfma && s.layers[0].w_mfma != nullptr) {
+        constexpr int TD = 3, TY = 4;
+        const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
+        dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
+        hipLaunchKernelGGL((k_conv3d_first8<TD, TY>), grid, block, 0, st, cost, s.layers[0].w_mfma, s.layers[0].bn_s,
+                           s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w, tiles_x, tiles_y);
+        LWS_LAUNCH_CHECK();
+        return LWS_OK;
+    }
+    if ((s.c3 == 16 || s.c3 == 32) && first_mfma && s.layers[0].w_mfma != nullptr) {
+        constexpr int TD = 3, TY = 4;
+        const int tiles_x = cdiv(w, 16), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
+        dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
+        if (s.c3 == 32)
+            hipLaunchKernelGGL((k_conv3d_first16<32, TD, TY>), grid, block, 0, st, cost, s.layers[0].w_mfma, s.layers[0].bn_s,
+                               s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w, tiles_x, tiles_y);
+        else
+            hipLaunchKernelGGL((k_conv3d_first16<16, TD, TY>), grid, block, 0, st, cost, s.layers[0].w_mfma, s.layers[0].bn_s,
+                               s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w, tiles_x, tiles_y);
+        LWS_LAUNCH_CHECK();
+        return LWS_OK;
+    }
     switch (s.c3) {
         case 8: first_launch<8>(s, cost, act_out, B, D, h, w, st); break;
         case 16: first_launch<16>(s, cost, act_out, B, D, h, w, st); break;

@@ -8,6 +8,7 @@ sys.path.insert(0, '/root/repo')
 KERNELS = {  # name: (stamp id, translation unit, driver, arg)
     "mid16": (1, "conv3d", "stack", 0), "mid8s2": (2, "conv3d", "stack", 1), "mid8s3": (2, "conv3d", "stack", 2),
     "last1": (3, "conv3d", "stack", 0), "last3": (3, "conv3d", "stack", 2),
+    "first1": (4, "conv3d", "stack", 0), "first3": (4, "conv3d", "stack", 2),
     
     "dws": (5, "conv2d", "refine", None), "conv64": (6, "conv2d", "refine", None),
     "feat": (7, "conv2d", "feat", None), "pair0": (13, "conv2d", "feat", None), "pair1": (14, "conv2d", "feat", None),
