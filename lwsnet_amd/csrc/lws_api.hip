@@ -225,11 +225,11 @@ static void prof_clear(lws_ctx *h)
 // low != nullptr: the soft-argmin is wanted too; *fused tells the caller whether it was done here
 static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost_out, float *act_a, float *act_b,
                         int B, int D, int hh, int ww, hipStream_t st, float *low = nullptr, float start = 0.f,
-                        bool *fused = nullptr)
+                        bool *fused = nullptr, bool first_done = false)
 {
     const Stage3d &s = h->stage[stage];
-    int rc;
-    {
+    int rc = LWS_OK;
+    if (!first_done) {     // (first_done: act_a already holds the first layer's output, see launch_shift_first)
         ProfScope p(h, LWS_KC_CONV3D_FIRST, st);
         rc = launch_conv3d_first(s, cost_in, act_a, B, D, hh, ww, st);
     }
@@ -631,7 +631,16 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         stage_dims(h, s, H, W, D, hh, ww);
         float *low = h->ws + L.low[s];
         if (s > 0 && feat_ready != nullptr) LWS_HIP(hipStreamWaitEvent(st, feat_ready[s], 0));
-        if (s == 0) {
+        static const int fuse_env = getenv("LWS_FUSE_SHIFT") ? atoi(getenv("LWS_FUSE_SHIFT")) : -1;
+        const bool fuse_shift = fuse_env != 0;      // default on (measured r01: +0.3 % at batch 1, +0.7 % at batch 8)
+        bool first_done = false;
+        if (s == 0 && fuse_shift && shift_first_can_fuse(h->stage[0], feat_c[0])) {
+            // stage-1 volume and the first Conv3D layer in one launch (the raw volume is still written: skip input)
+            ProfScope p(h, LWS_KC_CONV3D_FIRST, st);
+            rc = launch_shift_first(h->stage[0], featsL[0], featsR[0], raw, act_a, B, feat_c[0], D, hh, ww, st,
+                                    h->cfg.feature_fp16 != 0);                                                   // :131
+            first_done = true;
+        } else if (s == 0) {
             ProfScope p(h, LWS_KC_VOLUME_SHIFT, st);
             rc = launch_volume_l1_shift(featsL[0], featsR[0], raw, B, feat_c[0], hh, ww, D, st, h->cfg.feature_fp16 != 0);   // :131
         } else if (ds->def[s - 1]) {
@@ -648,7 +657,7 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         if (rc) return rc;
         const float start = s == 0 ? 0.0f : (float)(-h->cfg.maxdisplist[s] + 1);
         bool fused = false;
-        rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st, low, start, &fused);              // :136-138
+        rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st, low, start, &fused, first_done);  // :136-138
         if (rc) return rc;
         if (s == 0 && after_stage1_stack) {
             rc = after_stage1_stack();
@@ -1036,11 +1045,20 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
         LWS_HIP(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
         LWS_HIP(hipEventCreateWithFlags(&h->ev_right, hipEventDisableTiming | hipEventDisableSystemFence));
     }
-    LWS_HIP(hipEventRecord(h->ev_fork, st));
-    LWS_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    rc = refine_left(h, left, B, H, W, L, h->side);                                     // models.py:158
-    if (rc) return rc;
-    LWS_HIP(hipEventRecord(h->ev_join, h->side));
+    // refinement1_left (5 kernels, 58 us of HBM-bound work at batch 1) depends on the left image only.  Small batches
+    // run it on the side stream beside stages 2 and 3, whose MFMA kernels keep their weights in registers and do not
+    // mind; beside the feature head it spilled into stage 1, where k_conv3d_mid16's weight stream from L2 does mind
+    // (measured r01: 1,953 vs 1,934 pairs/s at batch 1).  Large batches are throughput-bound and keep the early start
+    // (2,778 vs 2,760 pairs/s at batch 8).  LWS_LEFT_AT=0|2 forces either.
+    static const int left_env = getenv("LWS_LEFT_AT") ? atoi(getenv("LWS_LEFT_AT")) : -1;
+    const int left_at = left_env >= 0 ? left_env : (B < 4 ? 2 : 0);
+    if (left_at == 0) {
+        LWS_HIP(hipEventRecord(h->ev_fork, st));
+        LWS_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        rc = refine_left(h, left, B, H, W, L, h->side);                                     // models.py:158
+        if (rc) return rc;
+        LWS_HIP(hipEventRecord(h->ev_join, h->side));
+    }
     float *f8 = h->ws + L.fe_f8, *f4 = h->ws + L.fe_f4, *f2 = h->ws + L.fe_f2;
     rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st, h->side, h->ev_feat);   // models.py:110-111
     if (rc) return rc;
@@ -1059,7 +1077,14 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     auto launch_tail = [&]() -> int {
         LWS_HIP(hipEventRecord(h->ev_feat[0], st));
         LWS_HIP(hipStreamWaitEvent(h->side, h->ev_feat[0], 0));
-        return feature_tail(h, 2 * B, H, W, L, f8, f4, f2, h->side, h->ev_feat, 2);
+        int r2 = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, h->side, h->ev_feat, 2);
+        if (r2) return r2;
+        if (left_at == 2) {
+            r2 = refine_left(h, left, B, H, W, L, h->side);
+            if (r2) return r2;
+            LWS_HIP(hipEventRecord(h->ev_join, h->side));
+        }
+        return LWS_OK;
     };
     DeferState ds;
     ds.allow_last = refine_can_defer(h);

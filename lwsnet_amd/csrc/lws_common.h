@@ -181,6 +181,9 @@ int launch_softargmin_upsample(const float *cost, const float *prev, float *out,
                                int w, int H, int W, float start, hipStream_t st);
 
 // conv3d stack pieces; activations are channels-last [B,D,h,w,C3]
+bool shift_first_can_fuse(const Stage3d &s, int C);
+int launch_shift_first(const Stage3d &s, const float *L, const float *R, float *cost, float *act_out, int B, int C, int D,
+                       int h, int w, hipStream_t st, bool q16);
 int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int B, int D, int h, int w,
                         hipStream_t st);
 // e0/e1 (optional, C3 % 16 == 0 only): events stamped with the kernel's own begin / end (hipExtLaunchKernelGGL)

@@ -15,6 +15,7 @@
 //   k_conv3d_mid8   C3 == 8          fp32 MFMA, M = (x parity, cout) so that all 16 MFMA rows work
 //   k_conv3d_last   C3 -> 1 + skip   VALU (K = 27*C3)
 #include <hip/hip_ext.h>
+#include <hip/hip_fp16.h>
 #include <stdlib.h>
 
 #include "lws_common.h"
@@ -591,8 +592,15 @@ __global__ __launch_bounds__(256) void k_conv3d_first8(const float *__restrict__
 // (n, g) of MFMA j supplies tap 4j+g of voxel n: one ds_read_b32 at a per-lane offset into the BN0+ReLU'd cost halo
 // tile, shared by the C3/16 output-channel tiles.  Taps ascending: the same chain as k_conv3d_first.
 // =============================================================================================
-template <int C3, int TD, int TY>
-__global__ __launch_bounds__(256) void k_conv3d_first16(const float *__restrict__ cost,    // [B,D,h,w]
+// SHIFT != 0 (stage 1 inside lws_forward / lws_disparity_stages): the kernel also BUILDS the volume
+// (k_volume_l1_shift's arithmetic: cost = sum over c ascending of |L - R(x-d)|, occluded columns |L - 0|) -- the
+// feature rows of the tile's halo go to LDS, the (TD+2)(TY+2)18 cost values are evaluated from them (2.8x
+// recomputation of a cheap volume), the tile's own values are written out (`cost` is then the OUTPUT: the raw volume
+// is the stack's skip input) and one launch disappears.  SHIFT == 2: features rounded to fp16 (BASELINE config 5).
+template <int C3, int TD, int TY, int SHIFT>
+__global__ __launch_bounds__(256) void k_conv3d_first16(float *__restrict__ cost,          // [B,D,h,w] (in; out if SHIFT)
+                                                        const float *__restrict__ featL,   // SHIFT: [B,16,h,w]
+                                                        const float *__restrict__ featR,
                                                         const float *__restrict__ wpk,     // [C3/16][7][64] A fragments
                                                         const float *__restrict__ bn0_s, const float *__restrict__ bn0_t,
                                                         const float *__restrict__ bn_s,    // next layer BN [C3]
@@ -612,16 +620,65 @@ __global__ __launch_bounds__(256) void k_conv3d_first16(const float *__restrict_
     const int td = tile / tiles_y;
     const int b = blockIdx.y;
     const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
-    const float *cb = cost + (int64_t)b * D * h * w;
+    float *cb = cost + (int64_t)b * D * h * w;
+    constexpr int FC = 16, RWD = HX + HD - 1;                      // feature channels; width of the R row window
+    constexpr int NL = FC * HY * HX, NR = FC * HY * RWD;
+    __shared__ float sF[SHIFT ? NL + NR : 1];
     float c[SITER];
     bool okv[SITER];
+    if (SHIFT) {
+        // feature rows y0-1 .. y0+TY of L (columns x0-1 .. x0+16) and R (columns shifted by d0-1 .. d0+TD)
+        constexpr int IL = (NL + 255) / 256, IR = (NR + 255) / 256;
+        const int64_t plane = (int64_t)h * w;
+        const float *Lb = featL + (int64_t)b * FC * plane, *Rb = featR + (int64_t)b * FC * plane;
+        float vl[IL], vr[IR];
+        bool okl[IL], okr[IR];
 #pragma unroll
-    for (int i = 0; i < SITER; ++i) {
-        const int v = tid + i * 256;
-        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
-        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        okv[i] = v < NVOX && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        c[i] = cb[okv[i] ? ((int64_t)gd * h + gy) * w + gx : 0];
+        for (int i = 0; i < IL; ++i) {
+            const int j = tid + i * 256;
+            const int ch = j / (HY * HX), hy = (j / HX) % HY, hx = j % HX;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            okl[i] = j < NL && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            vl[i] = Lb[okl[i] ? (int64_t)ch * plane + (int64_t)gy * w + gx : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < IR; ++i) {
+            const int j = tid + i * 256;
+            const int ch = j / (HY * RWD), hy = (j / RWD) % HY, jx = j % RWD;
+            const int gy = y0 + hy - 1, gx = x0 - 1 - d0 - TD + jx;
+            okr[i] = j < NR && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            vr[i] = Rb[okr[i] ? (int64_t)ch * plane + (int64_t)gy * w + gx : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < IL; ++i)
+            if (tid + i * 256 < NL) sF[tid + i * 256] = okl[i] ? (SHIFT == 2 ? __half2float(__float2half_rn(vl[i])) : vl[i]) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < IR; ++i)
+            if (tid + i * 256 < NR) sF[NL + tid + i * 256] = okr[i] ? (SHIFT == 2 ? __half2float(__float2half_rn(vr[i])) : vr[i]) : 0.0f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int v = tid + i * 256, vc = v < NVOX ? v : 0;
+            const int hx = vc % HX, t2 = vc / HX, hy = t2 % HY, hd = t2 / HY;
+            const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            okv[i] = v < NVOX && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            const float *lp = sF + hy * HX + hx, *rp = sF + NL + hy * RWD + hx - hd + TD + 1;
+            float acc = 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < FC; ++ch) acc = acc + fabsf(lp[ch * HY * HX] - rp[ch * HY * RWD]);
+            c[i] = acc;
+            if (okv[i] && hd >= 1 && hd <= TD && hy >= 1 && hy <= TY && hx >= 1 && hx <= 16)
+                cb[((int64_t)gd * h + gy) * w + gx] = acc;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int v = tid + i * 256;
+            const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+            const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            okv[i] = v < NVOX && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            c[i] = cb[okv[i] ? ((int64_t)gd * h + gy) * w + gx : 0];
+        }
     }
     const float s0 = bn0_s[0], t0 = bn0_t[0];
     float4 es[MT], et[MT];
@@ -852,6 +909,38 @@ static void first_launch(const Stage3d &s, const float *cost, float *act, int B,
                        s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act, D, h, w);
 }
 
+bool shift_first_can_fuse(const Stage3d &s, int C)
+{
+    return C == 16 && (s.c3 == 16 || s.c3 == 32) && !s.layers.empty() && s.layers[0].w_mfma != nullptr;
+}
+
+// stage-1 volume (written to `cost`: the stack's skip input) + first Conv3D layer in one launch
+int launch_shift_first(const Stage3d &s, const float *L, const float *R, float *cost, float *act_out, int B, int C, int D,
+                       int h, int w, hipStream_t st, bool q16)
+{
+    if (!shift_first_can_fuse(s, C)) {
+        set_error("shift_first: unsupported channels C=%d c3=%d", C, s.c3);
+        return LWS_ERR_INVALID;
+    }
+    constexpr int TD = 3, TY = 4;
+    const int tiles_x = cdiv(w, 16), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
+    dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
+#define LWS_SF(C3v, SH)                                                                                               \
+    hipLaunchKernelGGL((k_conv3d_first16<C3v, TD, TY, SH>), grid, block, 0, st, cost, L, R, s.layers[0].w_mfma,        \
+                       s.layers[0].bn_s, s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w,      \
+                       tiles_x, tiles_y)
+    if (s.c3 == 32) {
+        if (q16) LWS_SF(32, 2);
+        else LWS_SF(32, 1);
+    } else {
+        if (q16) LWS_SF(16, 2);
+        else LWS_SF(16, 1);
+    }
+#undef LWS_SF
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
 int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int B, int D, int h, int w,
                         hipStream_t st)
 {
@@ -872,12 +961,16 @@ int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int
         constexpr int TD = 3, TY = 4;
         const int tiles_x = cdiv(w, 16), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
         dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
+        float *cin = const_cast<float *>(cost);     // SHIFT = 0: read only
+        const float *nofeat = nullptr;
         if (s.c3 == 32)
-            hipLaunchKernelGGL((k_conv3d_first16<32, TD, TY>), grid, block, 0, st, cost, s.layers[0].w_mfma, s.layers[0].bn_s,
-                               s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w, tiles_x, tiles_y);
+            hipLaunchKernelGGL((k_conv3d_first16<32, TD, TY, 0>), grid, block, 0, st, cin, nofeat, nofeat, s.layers[0].w_mfma,
+                               s.layers[0].bn_s, s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w,
+                               tiles_x, tiles_y);
         else
-            hipLaunchKernelGGL((k_conv3d_first16<16, TD, TY>), grid, block, 0, st, cost, s.layers[0].w_mfma, s.layers[0].bn_s,
-                               s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w, tiles_x, tiles_y);
+            hipLaunchKernelGGL((k_conv3d_first16<16, TD, TY, 0>), grid, block, 0, st, cin, nofeat, nofeat, s.layers[0].w_mfma,
+                               s.layers[0].bn_s, s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w,
+                               tiles_x, tiles_y);
         LWS_LAUNCH_CHECK();
         return LWS_OK;
     }

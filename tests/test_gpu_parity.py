@@ -381,7 +381,8 @@ def test_profiler_counts_and_sampling(dev, model, hip_lib):
     _lib.check(hip_lib.lws_profile_read(model._h, tot, cnt))
     got = dict(zip(names, list(cnt)))
     assert got["conv3d_mid16"] == 4 and got["conv3d_mid8"] == 8 and got["conv3d_first"] == 3 and got["conv3d_last"] == 3
-    assert got["volume_l1_shift"] == 1 and got["volume_l1_warp"] == 2 and got["ref_conv64"] == 1 and got["ref_dws"] == 12
+    # (the stage-1 volume is built inside the first Conv3D launch unless LWS_FUSE_SHIFT=0)
+    assert got["volume_l1_shift"] in (0, 1) and got["volume_l1_warp"] == 2 and got["ref_conv64"] == 1 and got["ref_dws"] == 12
     assert all(t >= 0.0 for t in tot) and tot[names.index("conv3d_mid16")] > 0.0
     # sampling: 6 calls, every 3rd recorded -> 2 forwards' worth of mid16 launches
     _lib.check(hip_lib.lws_profile_enable(model._h, 1 << names.index("conv3d_mid16")))
