@@ -215,6 +215,18 @@ def test_forward_batch_paths_agree(dev, model):
             assert torch.equal(p1[s], p3[s][i:i + 1]), f"pair {i} stage {s + 1}"
 
 
+def test_forward_repeatable(dev, model):
+    """lws_forward overlaps a side stream (refinement1_left, the feature tail) with the critical chain through events:
+    back-to-back forwards without host synchronisation must reproduce the same bits (tools/soak.py runs longer)."""
+    for B, H, W in [(1, 256, 512), (3, 64, 256)]:
+        left, right = make_batch(B, H, W, 21)
+        ref = [p.clone() for p in model(left, right)]
+        for it in range(25):
+            out = model(left, right)
+            for s in range(4):
+                assert torch.equal(out[s], ref[s]), f"B={B} iteration {it} stage {s + 1}"
+
+
 def test_forward_matches_literal_oracle(dev, model):
     """LWSNet.forward end to end (all kernels native) vs the literal oracle's golden stage maps."""
     g = golden("e2e_64x256.npz")
