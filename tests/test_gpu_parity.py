@@ -227,6 +227,38 @@ def test_forward_repeatable(dev, model):
                 assert torch.equal(out[s], ref[s]), f"B={B} iteration {it} stage {s + 1}"
 
 
+@pytest.mark.parametrize("H,W", [(8, 192), (24, 200), (40, 264)])
+def test_forward_small_and_ragged_sizes(dev, model, H, W):
+    """Smallest legal input (W/8 == maxdisplist[0], one row of stage-1 tiles) and sizes whose stage maps are not
+    multiples of any tile (25 / 50 / 100 columns; 33 / 66 / 132): every stage map equals the C oracle bit for bit."""
+    from oracle import c_oracle as C
+    left, right = make_batch(1, H, W, 5)
+    pred = model(left, right)
+    want = C.forward(left, right, model.state_dict())
+    for s in range(4):
+        assert_bits(pred[s], want[s], f"{H}x{W} stage {s + 1}")
+
+
+@pytest.mark.parametrize("kind", ["zeros", "constant", "huge"])
+def test_forward_degenerate_inputs(dev, model, kind):
+    """All-zero and constant images (every hypothesis has the same cost: the soft-argmin is an exact tie) and inputs
+    1e4 times the normalised range (large costs: exp underflow in all but the best hypothesis)."""
+    from oracle import c_oracle as C
+    H, W = 32, 256
+    if kind == "zeros":
+        left = right = np.zeros((1, 3, H, W), np.float32)
+    elif kind == "constant":
+        left = right = np.full((1, 3, H, W), 0.75, np.float32)
+    else:
+        left, right = make_batch(1, H, W, 9)
+        left, right = left * 1e4, right * 1e4
+    pred = model(left, right)
+    want = C.forward(left, right, model.state_dict())
+    for s in range(4):
+        assert torch.isfinite(pred[s]).all()
+        assert_bits(pred[s], want[s], f"{kind} stage {s + 1}")
+
+
 def test_forward_matches_literal_oracle(dev, model):
     """LWSNet.forward end to end (all kernels native) vs the literal oracle's golden stage maps."""
     g = golden("e2e_64x256.npz")
