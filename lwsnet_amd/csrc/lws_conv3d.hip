@@ -128,6 +128,8 @@ __global__ __launch_bounds__(256) void k_conv3d_first(const float *__restrict__ 
 // Each wave owns TD*TY/4 rows x all C3/16 output-channel tiles: (TD*TY/4)*(C3/16) independent
 // accumulator chains, which covers the 40-cycle dependent-issue latency of the 32-cycle MFMA.
 // =============================================================================================
+constexpr bool MID16_INTERLEAVE = true;   // see the inner loop of k_conv3d_mid16
+
 template <int C3, int TD, int TY, int WR, int WM>
 struct Mid16Cfg {
     static constexpr int MT = C3 / 16;          // output-channel tiles of the layer
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
 #pragma unroll
                         for (int mt = 0; mt < MTW; ++mt)
                             acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4(wbuf[kw][q][mt], j), f4(bc[r], j), acc[r][mt], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (!MID16_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
                     // prefetch slice j: one activation fragment per slice, then (on the first channel group of a tap)
                     // the weights of the next tap
                     if (j < RW) bn[j] = *reinterpret_cast<const float4 *>(rptr[j] + off_n);
@@ -314,6 +316,21 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
                                 const int q2 = l / MTW, mt2 = l % MTW;
                                 wbuf[(kw + 1) % 3][q2][mt2] = wtap[((kw + 1) * Q + q2) * MT * 64 + mt2 * 64];
                             }
+                    }
+                    if (MID16_INTERLEAVE) {
+                        // one prefetch instruction per MFMA gap instead of all of them behind the group: an MFMA leaves
+                        // ~24 issue cycles free, a ds_read plus two global loads plus their address adds need ~50
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU (address)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
