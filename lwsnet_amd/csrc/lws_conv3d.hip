@@ -230,14 +230,17 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
 #pragma unroll
     for (int i = 0; i < P1; ++i) stage_write(i);
 
-    // weights of this wave: [tap][q][mt][lane] float4, mt in [wm*MTW, (wm+1)*MTW); the packed array holds one
-    // extra all-zero tap so that the "next tap" prefetch never needs a bounds check
+    // weights of this wave: [tap][q][mt][lane] float4, mt in [wm*MTW, (wm+1)*MTW); the packed array holds two
+    // extra all-zero taps so that the two-taps-ahead prefetch never needs a bounds check
     const float4 *wp = wpk + (wm * MTW) * 64 + lane;
     float4 wbuf[3][Q][MTW];                         // ring over kw: tap kw of the current (kd,kh) lives in wbuf[kw]
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) wbuf[0][q][mt] = wp[(q * MT + mt) * 64];
+        for (int mt = 0; mt < MTW; ++mt) {
+            wbuf[0][q][mt] = wp[(q * MT + mt) * 64];
+            wbuf[1][q][mt] = wp[((Q + q) * MT + mt) * 64];     // the stream runs two taps ahead of the MFMAs
+        }
     __syncthreads();
     LWS_STAMPK(1, 1);
 
@@ -308,13 +311,14 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
                         for (int r = 4; r < RW; ++r) bn[r] = *reinterpret_cast<const float4 *>(rptr[r] + off_n);
                     }
                     if (q == 0 && j >= 1) {
-                        // tap t+1 -> wbuf[(kw+1)%3]; Q*MTW loads spread over slices 1..3
+                        // tap t+2 -> wbuf[(kw+2)%3] (the slot of tap t-1): two taps = 4 steps = ~3k cycles of lead over
+                        // the L2 latency; Q*MTW loads spread over slices 1..3
                         constexpr int NL = Q * MTW;
 #pragma unroll
                         for (int l = 0; l < NL; ++l)
                             if (l % 3 == j - 1) {
                                 const int q2 = l / MTW, mt2 = l % MTW;
-                                wbuf[(kw + 1) % 3][q2][mt2] = wtap[((kw + 1) * Q + q2) * MT * 64 + mt2 * 64];
+                                wbuf[(kw + 2) % 3][q2][mt2] = wtap[((kw + 2) * Q + q2) * MT * 64 + mt2 * 64];
                             }
                     }
                     if (MID16_INTERLEAVE) {
@@ -881,7 +885,7 @@ __global__ __launch_bounds__((LastCfg<C3, TD, TY, TX, FUSE>::NT)) void k_conv3d_
 size_t packed_mid_weight_floats(int c3)
 {
     if (c3 == 8) return 72 * 64;
-    return (size_t)28 * c3 * c3;   // 27 taps + one all-zero tap (branch-free "next tap" prefetch in k_conv3d_mid16)
+    return (size_t)29 * c3 * c3;   // 27 taps + two all-zero taps (branch-free two-taps-ahead prefetch in k_conv3d_mid16)
 }
 
 // w: [cout][cin][27] (Conv3D weight [Cout,Cin,3,3,3] flattened)
