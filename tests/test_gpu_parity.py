@@ -259,6 +259,22 @@ def test_forward_degenerate_inputs(dev, model, kind):
         assert_bits(pred[s], want[s], f"{kind} stage {s + 1}")
 
 
+def test_forward_other_constructor_args(dev, hip_lib):
+    """LWSNet(args) with non-default layers_3d / growth_rate / maxdisplist (models/models.py:8-14): stage 1 with 16
+    channels (k_conv3d_mid16<16>, k_conv3d_first16<16>), 3 middle layers, residual ranges 3 and 4 (D = 5, 7: the
+    last layer is not fused with the soft-argmin).  Bit-exact against the C oracle."""
+    from lwsnet_amd.models import LWSNet
+    from oracle import c_oracle as C
+    args = default_args(maxdisplist=(24, 3, 4), layers_3d=3, channels_3d=8, growth_rate=(2, 1, 1))
+    sd = make_state_dict(11, args, calibrated=False)
+    m = LWSNet(args, device=dev).set_state_dict(sd).eval()
+    left, right = make_batch(1, 32, 256, 4)
+    pred = m(left, right)
+    want = C.forward(left, right, sd, maxdisplist=(24, 3, 4))
+    for s in range(4):
+        assert_bits(pred[s], want[s], f"non-default args, stage {s + 1}")
+
+
 def test_forward_matches_literal_oracle(dev, model):
     """LWSNet.forward end to end (all kernels native) vs the literal oracle's golden stage maps."""
     g = golden("e2e_64x256.npz")
