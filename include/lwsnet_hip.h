@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LWS_ABI_VERSION 3
+#define LWS_ABI_VERSION 4
 
 typedef enum {
     LWS_OK = 0,
@@ -121,6 +121,17 @@ int lws_refine(lws_handle h, const float *left, const float *pred3, int B, int H
 /* LWSNet.forward, models/models.py:106-164: left, right [B,3,H,W] -> pred_out[0..3] [B,1,H,W]. */
 int lws_forward(lws_handle h, const float *left, const float *right, int B, int H, int W, float *const pred_out[4],
                 void *stream);
+
+/* Launch-plan options of lws_forward / lws_disparity_stages.  They change which kernels / streams carry the work, never
+ * the arithmetic: every setting returns the same bits (tests/test_gpu_parity.py::test_forward_schedule_options).
+ *   "left_at"        -1 (default: by batch), 0 = refinement1_left starts with the forward, 2 = beside stages 2-3
+ *   "split_heads"    -1 (default: batches >= 4), 0/1 = right-image feature head on its own stream
+ *   "fuse_shift"     1 (default) = stage-1 volume built inside the first Conv3D launch
+ *   "fuse_first"     1 (default) = refinement1_disp's 1 -> 32 convolution inside its first depthwise block
+ *   "defer_upsample" 1 (default) = at batches <= 2 the consumers evaluate the stage-2/3 maps
+ * Unknown names and out-of-range values return LWS_ERR_INVALID. */
+int lws_set_option(lws_handle h, const char *name, int value);
+int lws_get_option(lws_handle h, const char *name, int *value);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------ */
 /* Kernel classes timed by the built-in profiler. */

@@ -42,6 +42,8 @@ PROTOTYPES = {
     "lws_feature_extraction": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lws_refine": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lws_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp * 4, _vp]),
+    "lws_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
+    "lws_get_option": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(_i)]),
     "lws_profile_enable": (_i, [_vp, _i]),
     "lws_profile_sample": (_i, [_vp, _i]),
     "lws_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), c_int64_p]),
@@ -71,7 +73,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lws_abi_version() != 3:
+    if lib.lws_abi_version() != 4:
         raise RuntimeError("liblwsnet_hip.so ABI version mismatch; rebuild the extension")
     _lib = lib
     return lib

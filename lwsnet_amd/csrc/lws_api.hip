@@ -419,6 +419,9 @@ static void bind_net2d(lws_ctx *h, const Net2dOffsets &o)
     n.r2_last = h->params + o.r2_last;
 }
 
+// right-image feature head on its own stream? (auto: batches >= 4)
+static bool split_heads(const lws_ctx *h, int B) { return h->opt.split_heads >= 0 ? h->opt.split_heads != 0 : B >= 4; }
+
 // feature_extraction.forward (submodules.py:176-188) on N images; first layer may read two separate inputs
 static int feature_tail(lws_ctx *h, int N, int H, int W, const WsLayout &L, float *f8, float *f4, float *f2,
                         hipStream_t st, hipEvent_t *ev, int part = 3);
@@ -443,34 +446,17 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
     if (rc) return rc;
     // layers up to the 1/8 map (dres0, dres1, hourglass conv1..conv4) for `cnt` images starting at batch index i0 on
     // stream s; images [0, n1) are read from img, the rest from img2.  Consecutive layers run pairwise in one launch
-    // (k_conv2d_pair, bit-identical to one kernel per layer); LWS_PAIR=0 selects one kernel per layer.  Measured r01 on
-    // MI355X after the scalar-weight fix: 1,704 vs 1,688 pairs/s at B = 1, 2,750 vs 2,730 at B = 8, 749 vs 753 at
-    // B = 8 368x1232 -- four launches fewer on the critical path against the halo recompute of the first layer.
-    static const bool no_pair = [] {
-        const char *e = getenv("LWS_PAIR");
-        return e != nullptr && atoi(e) == 0;
-    }();
+    // (k_conv2d_pair / k_conv2d_pair_mfma, the same fma chains as one kernel per layer).
     auto head = [&](hipStream_t s, const float *img, const float *img2, int n1, int i0, int cnt) -> int {
         hipStream_t st = s;   // (the profiling macro names the stream `st`)
         const size_t q2 = (size_t)i0 * H2 * W2, q4 = (size_t)i0 * H4 * W4, q8 = (size_t)i0 * H8 * W8;
-        if (no_pair) {
-            LWS_FE(launch_conv2d_nchw(n.fe[0], img, nullptr, a0 + 4 * q2, cnt, H, W, st, img2, n1));            // dres0.0
-            LWS_FE(launch_conv2d_nchw(n.fe[1], a0 + 4 * q2, nullptr, o + 8 * q2, cnt, H2, W2, st));             // dres0.2
-            LWS_FE(launch_conv2d_nchw(n.fe[2], o + 8 * q2, nullptr, a2 + 4 * q2, cnt, H2, W2, st));             // dres1.0
-            LWS_FE(launch_conv2d_nchw(n.fe[3], a2 + 4 * q2, o + 8 * q2, o2 + 8 * q2, cnt, H2, W2, st));         // dres1.2 + o (:179)
-            LWS_FE(launch_conv2d_nchw(n.fe[4], o2 + 8 * q2, nullptr, c1 + 16 * q4, cnt, H2, W2, st));           // conv1 (1/4)
-            LWS_FE(launch_conv2d_nchw(n.fe[5], c1 + 16 * q4, nullptr, pre + 16 * q4, cnt, H4, W4, st));         // conv2 -> pre
-            LWS_FE(launch_conv2d_nchw(n.fe[6], pre + 16 * q4, nullptr, c3 + 16 * q8, cnt, H4, W4, st));         // conv3 (1/8)
-            LWS_FE(launch_conv2d_nchw(n.fe[7], c3 + 16 * q8, nullptr, f8 + 16 * q8, cnt, H8, W8, st));          // conv4 -> f8
-            return LWS_OK;
-        }
         LWS_FE(launch_conv2d_pair(n.fe[0], n.fe[1], img, nullptr, o + 8 * q2, cnt, H, W, st, img2, n1));         // dres0
         LWS_FE(launch_conv2d_pair(n.fe[2], n.fe[3], o + 8 * q2, o + 8 * q2, o2 + 8 * q2, cnt, H2, W2, st));      // dres1 + o (:179)
         LWS_FE(launch_conv2d_pair(n.fe[4], n.fe[5], o2 + 8 * q2, nullptr, pre + 16 * q4, cnt, H2, W2, st));      // conv1, conv2 -> pre
         LWS_FE(launch_conv2d_pair(n.fe[6], n.fe[7], pre + 16 * q4, nullptr, f8 + 16 * q8, cnt, H4, W4, st));     // conv3, conv4 -> f8
         return LWS_OK;
     };
-    if (tail != nullptr && nB >= 4 && h->side2 != nullptr) {
+    if (tail != nullptr && split_heads(h, nB) && h->side2 != nullptr) {
         // left and right images are independent up to the cost volume: for batches >= 4 pairs the right images'
         // layers run on a second side stream and join before f8 is consumed (measured r01: +4 % at B = 8, but
         // -11 % at B = 1, where the two half-size launches only add dispatch overhead: there they stay batched)
@@ -563,11 +549,7 @@ static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLa
     const Net2d &n = h->net2d;
     float *ra = h->ws + L.r_a, *rb = h->ws + L.r_b, *rc_ = h->ws + L.r_c;
     int rc;
-    static const bool fuse_first = [] {
-        const char *e = getenv("LWS_FUSE_FIRST");
-        return e ? atoi(e) != 0 : true;
-    }();
-    if (fuse_first && ref_first_dws_can_fuse(n.r1[1][0], 1)) {
+    if (h->opt.fuse_first && ref_first_dws_can_fuse(n.r1[1][0], 1)) {
         // refinement1_disp: the 1 -> 32 convolution is recomputed inside the first block's staging (one launch less)
         if (ds != nullptr && ds->def[2]) {
             // pred3 = upsample(low[2]) + pred2 was not materialised: this kernel evaluates it and writes it out
@@ -595,11 +577,7 @@ static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLa
 
 static bool refine_can_defer(const lws_ctx *h)
 {
-    static const bool fuse_first = [] {
-        const char *e = getenv("LWS_FUSE_FIRST");
-        return e ? atoi(e) != 0 : true;
-    }();
-    return fuse_first && h->have_2d && ref_first_dws_can_fuse(h->net2d.r1[1][0], 1);
+    return h->opt.fuse_first && h->have_2d && ref_first_dws_can_fuse(h->net2d.r1[1][0], 1);
 }
 
 static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *const featsR[3], int B, int H, int W,
@@ -619,10 +597,7 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
 {
     int rc;
     float *act_a = h->ws + L.act_a, *act_b = h->ws + L.act_b, *raw = h->ws + L.cost_raw, *cost = h->ws + L.cost_out;
-    static const bool defer_up = [] {
-        const char *e = getenv("LWS_DEFER_UPSAMPLE");
-        return e ? atoi(e) != 0 : true;
-    }();
+    const bool defer_up = h->opt.defer_upsample != 0;
     DeferState local;
     if (ds == nullptr) ds = &local;
     static const int feat_c[3] = {16, 16, 8};   // feature_extraction outputs, submodules.py:101,104,186
@@ -631,8 +606,7 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         stage_dims(h, s, H, W, D, hh, ww);
         float *low = h->ws + L.low[s];
         if (s > 0 && feat_ready != nullptr) LWS_HIP(hipStreamWaitEvent(st, feat_ready[s], 0));
-        static const int fuse_env = getenv("LWS_FUSE_SHIFT") ? atoi(getenv("LWS_FUSE_SHIFT")) : -1;
-        const bool fuse_shift = fuse_env != 0;      // default on (measured r01: +0.3 % at batch 1, +0.7 % at batch 8)
+        const bool fuse_shift = h->opt.fuse_shift != 0;   // default on (measured r01: +0.3 % at batch 1, +0.7 % at batch 8)
         bool first_done = false;
         if (s == 0 && fuse_shift && shift_first_can_fuse(h->stage[0], feat_c[0])) {
             // stage-1 volume and the first Conv3D layer in one launch (the raw volume is still written: skip input)
@@ -731,6 +705,42 @@ int lws_create(const lws_config *cfg, lws_handle *out)
     if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;   // no GPU: host-side calls still work
     (void)hipGetLastError();
     *out = h;
+    return LWS_OK;
+}
+
+static int *option_slot(lws_ctx *h, const char *name)
+{
+    struct { const char *name; int *slot; } tab[] = {{"left_at", &h->opt.left_at},
+                                                     {"split_heads", &h->opt.split_heads},
+                                                     {"fuse_shift", &h->opt.fuse_shift},
+                                                     {"fuse_first", &h->opt.fuse_first},
+                                                     {"defer_upsample", &h->opt.defer_upsample}};
+    for (auto &e : tab)
+        if (strcmp(e.name, name) == 0) return e.slot;
+    return nullptr;
+}
+
+int lws_set_option(lws_handle h, const char *name, int value)
+{
+    LWS_CHECK_ARG(h && name, "lws_set_option: null argument");
+    int *slot = option_slot(h, name);
+    LWS_CHECK_ARG(slot != nullptr, "lws_set_option: unknown option '%s'", name);
+    if (strcmp(name, "left_at") == 0)
+        LWS_CHECK_ARG(value == -1 || value == 0 || value == 2, "lws_set_option: left_at must be -1 (auto), 0 or 2 (got %d)", value);
+    else if (strcmp(name, "split_heads") == 0)
+        LWS_CHECK_ARG(value >= -1 && value <= 1, "lws_set_option: split_heads must be -1 (auto), 0 or 1 (got %d)", value);
+    else
+        LWS_CHECK_ARG(value == 0 || value == 1, "lws_set_option: %s must be 0 or 1 (got %d)", name, value);
+    *slot = value;
+    return LWS_OK;
+}
+
+int lws_get_option(lws_handle h, const char *name, int *value)
+{
+    LWS_CHECK_ARG(h && name && value, "lws_get_option: null argument");
+    int *slot = option_slot(h, name);
+    LWS_CHECK_ARG(slot != nullptr, "lws_get_option: unknown option '%s'", name);
+    *value = *slot;
     return LWS_OK;
 }
 
@@ -1049,11 +1059,13 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     // run it on the side stream beside stages 2 and 3, whose MFMA kernels keep their weights in registers and do not
     // mind; beside the feature head it spilled into stage 1, where k_conv3d_mid16's weight stream from L2 does mind
     // (measured r01: 1,953 vs 1,934 pairs/s at batch 1).  Large batches are throughput-bound and keep the early start
-    // (2,778 vs 2,760 pairs/s at batch 8).  LWS_LEFT_AT=0|2 forces either.
-    static const int left_env = getenv("LWS_LEFT_AT") ? atoi(getenv("LWS_LEFT_AT")) : -1;
-    const int left_at = left_env >= 0 ? left_env : (B < 4 ? 2 : 0);
+    // (2,778 vs 2,760 pairs/s at batch 8).  lws_set_option("left_at", 0|2) forces either.
+    const int left_at = h->opt.left_at >= 0 ? h->opt.left_at : (B < 4 ? 2 : 0);
+    // ev_fork orders both side streams behind everything already queued on st (the previous forward's readers of the
+    // buffers they overwrite, the producers of left/right): recorded whenever either consumer of it runs -- the early
+    // refinement1_left below or the right-image feature head on side2 (feature_extraction, batches >= 4)
+    if (left_at == 0 || split_heads(h, B)) LWS_HIP(hipEventRecord(h->ev_fork, st));
     if (left_at == 0) {
-        LWS_HIP(hipEventRecord(h->ev_fork, st));
         LWS_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
         rc = refine_left(h, left, B, H, W, L, h->side);                                     // models.py:158
         if (rc) return rc;

@@ -138,6 +138,14 @@ struct lws_prof_rec {
 
 struct lws_ctx {
     lws_config cfg;
+    // schedule options (lws_set_option): every setting computes the same bits, only the launch plan differs
+    struct {
+        int left_at = -1;          // refinement1_left on the side stream: 0 = from the start, 2 = beside stages 2-3, -1 = by batch
+        int split_heads = -1;      // right-image feature head on its own stream: -1 = batches >= 4
+        int fuse_shift = 1;        // stage-1 volume inside the first Conv3D launch
+        int fuse_first = 1;        // refinement1_disp's 1 -> 32 convolution inside its first depthwise block
+        int defer_upsample = 1;    // batches <= 2: consumers evaluate the stage-2/3 maps (no k_upsample_add launches)
+    } opt;
     unsigned prof_mask = 0;                  // kernel classes being timed in the current call
     unsigned prof_mask_cfg = 0;              // ... as configured by lws_profile_enable
     int prof_every = 1;                      // lws_profile_sample: lws_forward records events on every n-th call only

@@ -532,11 +532,7 @@ int launch_conv2d_pair(const Conv2dLayer &a, const Conv2dLayer &b, const float *
         n1 = N;
     }
     const int HA = (H + 2 * a.pad - 2 * a.dil - 1) / a.stride + 1, WA = (W + 2 * a.pad - 2 * a.dil - 1) / a.stride + 1;
-    static const bool use_mfma = [] {
-        const char *e = getenv("LWS_PAIR_MFMA");
-        return e ? atoi(e) != 0 : true;
-    }();
-    if (use_mfma && a.cout == 16 && b.cout == 16 && a.stride == 2 && a.dil == 1 && b.dil == 1 && res == nullptr &&
+    if (a.cout == 16 && b.cout == 16 && a.stride == 2 && a.dil == 1 && b.dil == 1 && res == nullptr &&
         a.w_mfma != nullptr && b.w_mfma != nullptr && (a.cin == 8 || a.cin == 16)) {
         if (a.cin == 8) return conv2d_pair_mfma_launch<8>(a, b, in, in2, n1, out, N, H, W, HA, WA, st);
         return conv2d_pair_mfma_launch<16>(a, b, in, in2, n1, out, N, H, W, HA, WA, st);
@@ -1067,10 +1063,6 @@ int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst,
 int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, float *out, int B, int H, int W,
                       hipStream_t st)
 {
-    static const int variant = [] {
-        const char *e = getenv("LWS_CONV64_VARIANT");
-        return e ? atoi(e) : 1;
-    }();
     const int dil = 8;
 #define LWS_C64(TYv, NWv)                                                                                          \
     {                                                                                                               \
@@ -1080,17 +1072,10 @@ int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, fl
                            reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby,                         \
                            use_wt_stores((size_t)B * H * W * 128));                                                 \
     }
-    // variant 1 (default): 8-row tiles, 4 waves x 2 rows (46 KB LDS: 3 workgroups per CU)   50.5 / 349 us at B = 1 / 8
-    // variant 0: 4-row tiles, 4 waves x 1 row (27 KB: 5 per CU; a weight fragment feeds 2 MFMAs)  54.3 / 390 us
-    // variant 2: 4-row tiles, 2 waves x 2 rows                                                    66.2 / 403 us
-    // variant 3: 2-row tiles, 1 wave x 2 rows (18 KB: 8 per CU)                                   53.8 / 408 us
-    // (measured r01, 256x512; the floor is 31 / 246 us of fp32 MFMA issue)
-    switch (variant) {
-        case 0: LWS_C64(4, 4); break;
-        case 2: LWS_C64(4, 2); break;
-        case 3: LWS_C64(2, 1); break;
-        default: LWS_C64(8, 4); break;
-    }
+    // 8-row tiles, 4 waves x 2 rows (46 KB LDS: 3 workgroups per CU): 50.5 / 349 us at B = 1 / 8 (r01, 256x512; the floor
+    // is 31 / 246 us of fp32 MFMA issue).  Measured and dropped: 4-row tiles x 4 waves 54.3 / 390 us, 4-row x 2 waves
+    // 66.2 / 403 us, 2-row x 1 wave 53.8 / 408 us.
+    LWS_C64(8, 4);
 #undef LWS_C64
     LWS_LAUNCH_CHECK();
     return LWS_OK;

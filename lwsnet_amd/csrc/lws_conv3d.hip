@@ -10,7 +10,7 @@
 // every output is ONE float32 fma chain from 0 over taps (kd,kh,kw) outer, input channel inner, ascending.
 // v_mfma_f32_16x16x4_f32 computes exactly such a k-ordered chain, so the MFMA kernels keep that contract.
 //
-//   k_conv3d_first  cin = 1  -> C3   VALU (K = 27)
+//   k_conv3d_first8 / k_conv3d_first16   cin = 1 -> C3   fp32 MFMA (K = 27 taps)
 //   k_conv3d_mid16  C3 % 16 == 0     fp32 MFMA implicit GEMM, M = cout tile, N = 16 voxels along x
 //   k_conv3d_mid8   C3 == 8          fp32 MFMA, M = (x parity, cout) so that all 16 MFMA rows work
 //   k_conv3d_last   C3 -> 1 + skip   VALU (K = 27*C3)
@@ -31,81 +31,6 @@ __device__ __forceinline__ float bn_relu(float x, float s, float t) { return fma
 
 // compile-time component select (j is always a constant after unrolling)
 __device__ __forceinline__ float f4(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
-
-// =============================================================================================
-// First layer: cost [B,D,h,w] -> act [B,D,h,w,C3].  One thread = one voxel x 8 output channels.
-// The 27 input taps come straight from L2 (the volume is at most a few MB); weights are broadcast
-// from LDS as [tap][cout].
-// =============================================================================================
-template <int C3>
-__global__ __launch_bounds__(256) void k_conv3d_first(const float *__restrict__ cost,
-                                                      const float *__restrict__ wgt,    // [C3][27]
-                                                      const float *__restrict__ bn0_s,  // BN of this layer [1]
-                                                      const float *__restrict__ bn0_t,
-                                                      const float *__restrict__ bn_s,   // next layer BN [C3]
-                                                      const float *__restrict__ bn_t,
-                                                      float *__restrict__ act, int D, int h, int w)
-{
-    // C3/8 threads per voxel, 8 output channels each: a wave stores whole 32 B / 128 B voxel lines.
-    constexpr int G = C3 / 8;
-    __shared__ __attribute__((aligned(16))) float sW[27 * C3];
-    LWS_STAMPK(4, 0);
-    for (int i = threadIdx.x; i < 27 * C3; i += 256) {
-        int tap = i / C3, co = i - tap * C3;
-        sW[i] = wgt[co * 27 + tap];
-    }
-    __syncthreads();
-    LWS_STAMPK(4, 1);
-    const float s0 = bn0_s[0], t0 = bn0_t[0];
-    const int64_t vol = (int64_t)D * h * w;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t v = idx / G;
-    const int grp = (int)(idx % G);
-    const int b = blockIdx.y;
-    if (v >= vol) return;
-    const int x = (int)(v % w);
-    const int y = (int)((v / w) % h);
-    const int d = (int)(v / ((int64_t)w * h));
-    const float *cb = cost + (int64_t)b * vol;
-    // epilogue BatchNorm, loaded together with the taps
-    const float4 sa = *reinterpret_cast<const float4 *>(bn_s + grp * 8), sb = *reinterpret_cast<const float4 *>(bn_s + grp * 8 + 4);
-    const float4 ta = *reinterpret_cast<const float4 *>(bn_t + grp * 8), tb = *reinterpret_cast<const float4 *>(bn_t + grp * 8 + 4);
-    float a[27];
-#pragma unroll
-    for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                int zd = d + kd - 1, zy = y + kh - 1, zx = x + kw - 1;
-                bool ok = zd >= 0 && zd < D && zy >= 0 && zy < h && zx >= 0 && zx < w;
-                const float ld = cb[ok ? ((int64_t)zd * h + zy) * w + zx : 0];
-                a[(kd * 3 + kh) * 3 + kw] = ok ? bn_relu(ld, s0, t0) : 0.0f;
-            }
-    float acc[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
-#pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-        const float4 w0 = *reinterpret_cast<const float4 *>(&sW[tap * C3 + grp * 8]);
-        const float4 w1 = *reinterpret_cast<const float4 *>(&sW[tap * C3 + grp * 8 + 4]);
-        acc[0] = fmaf(a[tap], w0.x, acc[0]);
-        acc[1] = fmaf(a[tap], w0.y, acc[1]);
-        acc[2] = fmaf(a[tap], w0.z, acc[2]);
-        acc[3] = fmaf(a[tap], w0.w, acc[3]);
-        acc[4] = fmaf(a[tap], w1.x, acc[4]);
-        acc[5] = fmaf(a[tap], w1.y, acc[5]);
-        acc[6] = fmaf(a[tap], w1.z, acc[6]);
-        acc[7] = fmaf(a[tap], w1.w, acc[7]);
-    }
-    LWS_STAMPK(4, 2);
-    float4 *out = reinterpret_cast<float4 *>(act + ((int64_t)b * vol + v) * C3 + grp * 8);
-    out[0] = make_float4(bn_relu(acc[0], sa.x, ta.x), bn_relu(acc[1], sa.y, ta.y), bn_relu(acc[2], sa.z, ta.z),
-                         bn_relu(acc[3], sa.w, ta.w));
-    out[1] = make_float4(bn_relu(acc[4], sb.x, tb.x), bn_relu(acc[5], sb.y, tb.y), bn_relu(acc[6], sb.z, tb.z),
-                         bn_relu(acc[7], sb.w, tb.w));
-    LWS_STAMPK(4, 3);
-}
 
 // =============================================================================================
 // Middle layers, C3 a multiple of 16 (stage 1: C3 = 32).
@@ -921,15 +846,6 @@ void pack_mid_weights(const float *w, int c3, float *out)
                     }
 }
 
-template <int C3>
-static void first_launch(const Stage3d &s, const float *cost, float *act, int B, int D, int h, int w, hipStream_t st)
-{
-    const int64_t vol = (int64_t)D * h * w * (C3 / 8);
-    dim3 grid((unsigned)((vol + 255) / 256), B), block(256);
-    hipLaunchKernelGGL(k_conv3d_first<C3>, grid, block, 0, st, cost, s.layers[0].w, s.layers[0].bn_s,
-                       s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act, D, h, w);
-}
-
 bool shift_first_can_fuse(const Stage3d &s, int C)
 {
     return C == 16 && (s.c3 == 16 || s.c3 == 32) && !s.layers.empty() && s.layers[0].w_mfma != nullptr;
@@ -965,11 +881,7 @@ int launch_shift_first(const Stage3d &s, const float *L, const float *R, float *
 int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int B, int D, int h, int w,
                         hipStream_t st)
 {
-    static const bool first_mfma = [] {
-        const char *e = getenv("LWS_FIRST_MFMA");
-        return e ? atoi(e) != 0 : true;
-    }();
-    if (s.c3 == 8 && first_mfma && s.layers[0].w_mfma != nullptr) {
+    if (s.c3 == 8 && s.layers[0].w_mfma != nullptr) {
         constexpr int TD = 3, TY = 4;
         const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
         dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
@@ -978,7 +890,7 @@ int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int
         LWS_LAUNCH_CHECK();
         return LWS_OK;
     }
-    if ((s.c3 == 16 || s.c3 == 32) && first_mfma && s.layers[0].w_mfma != nullptr) {
+    if ((s.c3 == 16 || s.c3 == 32) && s.layers[0].w_mfma != nullptr) {
         constexpr int TD = 3, TY = 4;
         const int tiles_x = cdiv(w, 16), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
         dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
@@ -995,14 +907,8 @@ int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int
         LWS_LAUNCH_CHECK();
         return LWS_OK;
     }
-    switch (s.c3) {
-        case 8: first_launch<8>(s, cost, act_out, B, D, h, w, st); break;
-        case 16: first_launch<16>(s, cost, act_out, B, D, h, w, st); break;
-        case 32: first_launch<32>(s, cost, act_out, B, D, h, w, st); break;
-        default: set_error("conv3d: unsupported channel count %d (8, 16, 32)", s.c3); return LWS_ERR_INVALID;
-    }
-    LWS_LAUNCH_CHECK();
-    return LWS_OK;
+    set_error("conv3d_first: unsupported channel count %d (8, 16, 32) or weights not packed", s.c3);
+    return LWS_ERR_INVALID;
 }
 
 template <int C3, int TD, int TY, int WR, int WM>
@@ -1061,29 +967,14 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
 {
     switch (s.c3) {
         case 8: {
-            // LWS_MID8_VARIANT=1 selects whole-D tiles (9 rows per wave).  Measured on MI355X (r01): 19.3 us vs
-            // 17.0 us for the 3-deep tile at B=1 256x512 -- one wave per SIMD cannot overlap its own staging with
-            // its MFMAs, three co-resident small workgroups can -- so the 3-deep tile is the default.
-            static const int variant = [] {
-                const char *e = getenv("LWS_MID8_VARIANT");
-                return e ? atoi(e) : 0;
-            }();
-            if (variant == 1 && D >= 9) return mid8_launch<9, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+            // (whole-D tiles, 9 rows per wave, measured r01: 19.3 vs 17.0 us at B=1 256x512 -- one wave per SIMD cannot
+            // overlap its own staging with its MFMAs, three co-resident small workgroups can)
             return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
         }
         case 16: return mid16_launch<16, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
         case 32: {
-            // tile/wave-layout variants (LWS_MID16_VARIANT is a development knob; default chosen by measurement)
-            static const int variant = [] {
-                const char *e = getenv("LWS_MID16_VARIANT");
-                return e ? atoi(e) : 0;
-            }();
-            switch (variant) {
-                case 1: return mid16_launch<32, 3, 4, 4, 2>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
-                case 2: return mid16_launch<32, 3, 2, 2, 2>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
-                case 3: return mid16_launch<32, 3, 8, 4, 2>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
-                default: return mid16_launch<32, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
-            }
+            // (8-wave workgroups <32,3,4,4,2> and half-height tiles <32,3,2,2,2> measured within 1 % of this, r01)
+            return mid16_launch<32, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
         }
         default: set_error("conv3d: unsupported channel count %d (8, 16, 32)", s.c3); return LWS_ERR_INVALID;
     }

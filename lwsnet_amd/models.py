@@ -95,6 +95,16 @@ class LWSNet:
 
     load_dict = set_state_dict
 
+    def set_option(self, name, value):
+        """Launch-plan option of the HIP library (include/lwsnet_hip.h: lws_set_option); results never change."""
+        _lib.check(_lib.load().lws_set_option(self._h, name.encode(), int(value)), "lws_set_option")
+        return self
+
+    def get_option(self, name):
+        v = ctypes.c_int(0)
+        _lib.check(_lib.load().lws_get_option(self._h, name.encode(), ctypes.byref(v)), "lws_get_option")
+        return v.value
+
     def _device_ctx(self):
         if self.device is None:
             import contextlib

@@ -127,18 +127,3 @@ def make_state_dict(seed=7, args=None, calibrated=True):
                     if key in sd and sd[key].shape == z[key].shape:
                         sd[key] = np.ascontiguousarray(z[key], dtype=np.float32)
     return sd
-
-
-def bn_scale_shift(sd, prefix, eps=1e-5):
-    """Eval-mode BatchNorm as ``y = x*s + t`` with float32 ``s, t``.
-
-    s = gamma / sqrt(var + eps), t = beta - mean*s, every step rounded to
-    float32 (this exact sequence is what the HIP library and the C oracle use).
-    """
-    g = sd[prefix + ".weight"].astype(np.float32)
-    b = sd[prefix + ".bias"].astype(np.float32)
-    m = sd[prefix + "._mean"].astype(np.float32)
-    v = sd[prefix + "._variance"].astype(np.float32)
-    s = (g / np.sqrt(v + np.float32(eps), dtype=np.float32)).astype(np.float32)
-    t = (b - (m * s).astype(np.float32)).astype(np.float32)
-    return s, t

@@ -33,6 +33,19 @@ def lib():
     return _lib
 
 
+def bn_scale_shift(sd, prefix, eps=1e-5):
+    """Eval-mode BatchNorm (submodules.py:18,196,226) as ``y = fmaf(x, s, t)`` with float32 ``s, t``:
+    s = gamma / sqrt(var + eps), t = beta - mean*s, every step rounded to float32 (the HIP library's host code
+    performs the same sequence in C++; the oracle keeps its own copy so that it does not import the product)."""
+    g = np.asarray(sd[prefix + ".weight"], dtype=np.float32)
+    b = np.asarray(sd[prefix + ".bias"], dtype=np.float32)
+    m = np.asarray(sd[prefix + "._mean"], dtype=np.float32)
+    v = np.asarray(sd[prefix + "._variance"], dtype=np.float32)
+    s = (g / np.sqrt(v + np.float32(eps), dtype=np.float32)).astype(np.float32)
+    t = (b - (m * s).astype(np.float32)).astype(np.float32)
+    return s, t
+
+
 def _p(a):
     return a.ctypes.data_as(_f) if a is not None else None
 
@@ -118,7 +131,6 @@ def upsample_add(low, prev, H, W):
 
 def conv3d_stack(cost, sd, stage):
     """cost [B,D,h,w] -> net(cost) + cost  (models.py:136-138)."""
-    from lwsnet_amd.weights import bn_scale_shift
     y = _c(cost)[:, None]
     j = 0
     while f"volume_postprocess.{stage}.{j}.2.weight" in sd:
@@ -193,7 +205,7 @@ def bn_add_relu(x, st=None, add=None, relu=False):
 
 def feature_extraction(x, sd):
     """submodules.py:176-188 with convbn's padding rule (:14): [1/8 (16 ch), 1/4 (16 ch), 1/2 (8 ch)]."""
-    from lwsnet_amd.weights import bn_scale_shift as bn
+    bn = bn_scale_shift
     fe = "feature_extraction"
 
     def convbn(v, name, stride, pad, dil, add=None, relu=True):
@@ -221,7 +233,7 @@ def feature_extraction(x, sd):
 
 def refine(left, pred3, sd):
     """models.py:158-162 + submodules.py:223-327: returns pred4 [B,1,H,W]."""
-    from lwsnet_amd.weights import bn_scale_shift as bn
+    bn = bn_scale_shift
 
     def dws(v, prefix, dil):
         v = conv2d(v, sd[prefix + ".2.weight"], 1, dil, dil, pre=bn(sd, prefix + ".0"), depthwise=True)

@@ -215,6 +215,88 @@ def test_forward_batch_paths_agree(dev, model):
             assert torch.equal(p1[s], p3[s][i:i + 1]), f"pair {i} stage {s + 1}"
 
 
+@pytest.mark.parametrize("B,H,W", [(4, 64, 256), (8, 64, 256), (4, 112, 1232), (8, 112, 1232)])
+def test_forward_large_batch_bitexact_vs_c_oracle(dev, model, B, H, W):
+    """Batches >= 4 (BASELINE configs 3 and 4 run 8 pairs per GPU) use a different launch plan: right-image feature head
+    on a second side stream, refinement1_left forked at the start, k_upsample_add launched (no deferred maps).  Every
+    stage map of every pair equals the C oracle bit for bit (models/models.py:106-164 is per-sample)."""
+    from oracle import c_oracle as C
+    left, right = make_batch(B, H, W, 31)
+    pred = model(left, right)
+    want = C.forward(left, right, model.state_dict())
+    for s in range(4):
+        assert_bits(pred[s], want[s], f"B={B} {H}x{W} stage {s + 1}")
+
+
+@pytest.mark.parametrize("H,W", [(256, 512), (368, 1232)])
+def test_forward_batch8_equals_single_pair_runs(dev, model, H, W):
+    """BASELINE config 4's per-GPU batch (8 x 256x512) and config 3 (8 x 368x1232): every pair of the batch-8 run equals
+    its own batch-1 run bitwise for all 4 stages.  (The batch-1 plan is pinned to the C oracle by the tests above;
+    the batch-8 plan at oracle-sized inputs by test_forward_large_batch_bitexact_vs_c_oracle.)"""
+    left, right = make_batch(8, H, W, 40)
+    p8 = model(left, right)
+    assert all(tuple(p.shape) == (8, 1, H, W) and torch.isfinite(p).all() for p in p8)
+    for i in range(8):
+        p1 = model(left[i:i + 1], right[i:i + 1])
+        for s in range(4):
+            assert torch.equal(p1[s], p8[s][i:i + 1]), f"{H}x{W} pair {i} stage {s + 1}"
+
+
+def test_forward_repeatable_batch8(dev, model):
+    """25 back-to-back batch-8 forwards without host synchronisation (three streams joined by events) reproduce the
+    same bits; then alternate with a batch-1 call (different plan, same handle and workspace)."""
+    left, right = make_batch(8, 256, 512, 50)
+    ref = [p.clone() for p in model(left, right)]
+    for it in range(25):
+        out = model(left, right)
+        for s in range(4):
+            assert torch.equal(out[s], ref[s]), f"iteration {it} stage {s + 1}"
+    one = [p.clone() for p in model(left[3:4], right[3:4])]
+    for it in range(5):
+        out8 = model(left, right)
+        out1 = model(left[3:4], right[3:4])
+        for s in range(4):
+            assert torch.equal(out8[s], ref[s]) and torch.equal(out1[s], one[s]), f"alternating {it} stage {s + 1}"
+            assert torch.equal(one[s], ref[s][3:4])
+
+
+OPTION_PLANS = [{"left_at": 0}, {"left_at": 2}, {"split_heads": 1}, {"split_heads": 0}, {"fuse_shift": 0},
+                {"fuse_first": 0}, {"defer_upsample": 0}, {"left_at": 2, "split_heads": 1},
+                {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0}]
+
+
+@pytest.mark.parametrize("plan", OPTION_PLANS, ids=lambda p: ",".join(f"{k}={v}" for k, v in p.items()))
+def test_forward_schedule_options(dev, hip_lib, plan):
+    """lws_set_option (include/lwsnet_hip.h) only moves work between launches / streams: for every plan the four stage
+    maps equal the C oracle bit for bit at batch 1, and the batch-1 / batch-3 / batch-5 results agree pair by pair
+    (batch 5 with left_at=2 + split_heads=1 is the combination ADVICE r1 flagged: side2 must be ordered behind the
+    previous forward even when refinement1_left does not fork at the start)."""
+    from lwsnet_amd.models import LWSNet
+    from oracle import c_oracle as C
+    m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
+    for k, v in plan.items():
+        m.set_option(k, v)
+        assert m.get_option(k) == v
+    left, right = make_batch(5, 64, 256, 61)
+    want = C.forward(left[:1], right[:1], m.state_dict())
+    p1 = m(left[:1], right[:1])
+    for s in range(4):
+        assert_bits(p1[s], want[s], f"{plan} stage {s + 1}")
+    for B in (3, 5):
+        ref = None
+        for it in range(6):                       # back to back: the side streams of call n+1 meet call n's readers
+            pb = m(left[:B], right[:B])
+            if ref is None:
+                ref = [p.clone() for p in pb]
+            assert all(torch.equal(pb[s], ref[s]) for s in range(4)), f"{plan} B={B} iteration {it}"
+        for s in range(4):
+            assert torch.equal(ref[s][:1], p1[s]), f"{plan} B={B} stage {s + 1}"
+    with pytest.raises(ValueError):
+        m.set_option("no_such_option", 1)
+    with pytest.raises(ValueError):
+        m.set_option("left_at", 1)
+
+
 def test_forward_repeatable(dev, model):
     """lws_forward overlaps a side stream (refinement1_left, the feature tail) with the critical chain through events:
     back-to-back forwards without host synchronisation must reproduce the same bits (tools/soak.py runs longer)."""
@@ -441,7 +523,7 @@ def test_profiler_counts_and_sampling(dev, model, hip_lib):
     _lib.check(hip_lib.lws_profile_read(model._h, tot, cnt))
     got = dict(zip(names, list(cnt)))
     assert got["conv3d_mid16"] == 4 and got["conv3d_mid8"] == 8 and got["conv3d_first"] == 3 and got["conv3d_last"] == 3
-    # (the stage-1 volume is built inside the first Conv3D launch unless LWS_FUSE_SHIFT=0)
+    # (the stage-1 volume is built inside the first Conv3D launch unless lws_set_option("fuse_shift", 0))
     assert got["volume_l1_shift"] in (0, 1) and got["volume_l1_warp"] == 2 and got["ref_conv64"] == 1 and got["ref_dws"] == 12
     assert all(t >= 0.0 for t in tot) and tot[names.index("conv3d_mid16")] > 0.0
     # sampling: 6 calls, every 3rd recorded -> 2 forwards' worth of mid16 launches

@@ -8,7 +8,8 @@ import torch
 
 from conftest import golden
 from lwsnet_amd.synth import make_pair
-from lwsnet_amd.weights import bn_scale_shift, make_state_dict, state_dict_spec
+from lwsnet_amd.weights import make_state_dict, state_dict_spec
+from oracle.c_oracle import bn_scale_shift
 from oracle import c_oracle as C
 from oracle import lws_oracle as O
 
