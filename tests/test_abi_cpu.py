@@ -26,7 +26,7 @@ def test_header_and_prototypes_agree():
 def test_library_exports_every_symbol(hip_lib):
     for name in _declared():
         assert hasattr(hip_lib, name), name
-    assert hip_lib.lws_abi_version() == 3
+    assert hip_lib.lws_abi_version() == 4
 
 
 def _create(lib, **kw):
@@ -95,3 +95,19 @@ def test_check_size_matches_reference_constraints():
     for H, W in ((375, 1242), (540, 960), (256, 128)):
         with pytest.raises(ValueError):
             check_size(H, W)
+
+
+def test_options_validate_names_and_ranges(hip_lib):
+    """lws_set_option / lws_get_option are host-side: they work without a GPU."""
+    rc, h = _create(hip_lib)
+    assert rc == 0
+    v = ctypes.c_int(123)
+    for name, default in [(b"left_at", -1), (b"split_heads", -1), (b"fuse_shift", 1), (b"fuse_first", 1), (b"defer_upsample", 1)]:
+        assert hip_lib.lws_get_option(h, name, ctypes.byref(v)) == 0 and v.value == default
+    assert hip_lib.lws_set_option(h, b"left_at", 2) == 0
+    assert hip_lib.lws_get_option(h, b"left_at", ctypes.byref(v)) == 0 and v.value == 2
+    assert hip_lib.lws_set_option(h, b"left_at", 1) == _lib.LWS_ERR_INVALID
+    assert hip_lib.lws_set_option(h, b"fuse_shift", 2) == _lib.LWS_ERR_INVALID
+    assert hip_lib.lws_set_option(h, b"bogus", 1) == _lib.LWS_ERR_INVALID
+    assert b"unknown option" in hip_lib.lws_last_error()
+    hip_lib.lws_destroy(h)
