@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Run the reference's OWN source (/root/reference/models/models.py, imported in place) on torch-CPU through a
+stand-in for the ~25 Paddle calls it makes (tools/paddle_shim.py), and
+
+  1. compare all four stage maps with the hand restatement oracle/lws_oracle.py (float32 and float64), for the default
+     constructor arguments and two non-default ones -- this executes the reference's control flow, layer wiring,
+     padding rules and state-dict names from the reference's text, so it removes the transcription risk of the
+     230-line restatement;
+  2. with --write, store the stage maps as tests/golden/ref_source_*.npz (inputs + float32 outputs + float64 outputs).
+     Provenance of those vectors: reference source text + torch-CPU kernels + the Paddle op defaults listed in
+     tools/paddle_shim.py (from memory of Paddle 2.0).  They are NOT PaddlePaddle outputs: the
+     oracle remains "parity unpinned" (DESIGN.md section 2).
+
+Build-container only: /root/reference does not exist on the GPU box and nothing here is imported by the product, the
+tests, bench.py or smoke().  Nothing from /root/reference is copied: the fixtures are numeric arrays.
+
+Usage: python tools/check_oracle_vs_reference.py [--write] [--reference /root/reference]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import paddle_shim                                   # noqa: E402
+from lwsnet_amd.synth import make_noise_pair, make_pair   # noqa: E402
+from lwsnet_amd.weights import default_args, make_state_dict   # noqa: E402
+from oracle import lws_oracle as O                   # noqa: E402
+
+CASES = [
+    # name, H, W, pair kind, constructor arguments, calibrated BN
+    ("e2e_64x256", 64, 256, "smooth", dict(), True),
+    ("e2e_noise_64x256", 64, 256, "noise", dict(), True),
+    ("e2e_d32_64x320", 64, 320, "smooth", dict(maxdisplist=(32, 5, 5)), True),
+    ("e2e_args_32x256", 32, 256, "smooth", dict(maxdisplist=(24, 3, 4), layers_3d=3, channels_3d=8, growth_rate=(2, 1, 1)), False),
+    ("e2e_odd_63x255", 63, 255, "smooth", dict(), True),      # H, W = 8k-1: legal for the reference (ceil(H/2) % 4 == 0)
+]
+
+
+def run_reference(ref_root, args, sd, left, right, dtype):
+    """LWSNet from the reference's source, float32 or float64 (the hard-coded dtype='float32' strings map to `dtype`)."""
+    paddle_shim.set_dtype(dtype)
+    paddle_shim.install()
+    if ref_root not in sys.path:
+        sys.path.insert(0, ref_root)
+    for m in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[m]
+    from models.models import LWSNet                 # the reference's file, imported in place
+    src = sys.modules["models.models"].__file__
+    assert os.path.realpath(src).startswith(os.path.realpath(ref_root)), src
+    model = LWSNet(args)
+    model.set_state_dict(sd)                         # raises on any key / shape mismatch with the reference's own layers
+    model.eval()
+    with torch.no_grad():
+        out = model(paddle_shim.to_tensor(left, "float32"), paddle_shim.to_tensor(right, "float32"))
+    assert isinstance(out, list) and len(out) == 4
+    return [o.numpy() for o in out], sorted(model.state_dict().keys())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--write", action="store_true")
+    a = ap.parse_args()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    worst = 0.0
+    for name, H, W, kind, kw, calib in CASES:
+        args = default_args(**kw)
+        sd = make_state_dict(7, args, calibrated=calib)
+        if kind == "noise":
+            l, r = make_noise_pair(H, W, 0)
+        else:
+            l, r, _ = make_pair(H, W, 0)
+        l, r = l[None], r[None]
+        ref32, keys = run_reference(a.reference, args, sd, l, r, torch.float32)
+        ref64, _ = run_reference(a.reference, args, sd, l, r, torch.float64)
+        assert keys == sorted(sd.keys()), "state-dict names differ from the reference's own layers"
+        ora32 = [p.numpy() for p in O.forward(l, r, sd, args.maxdisplist, torch.float32)]
+        ora64 = [p.numpy() for p in O.forward(l, r, sd, args.maxdisplist, torch.float64)]
+        d32 = [float(np.abs(x - y).max()) for x, y in zip(ref32, ora32)]
+        d64 = [float(np.abs(x - y).max()) for x, y in zip(ref64, ora64)]
+        n32 = [float(np.abs(x.astype(np.float64) - y).max()) for x, y in zip(ref32, ref64)]
+        print(f"{name:18s} reference-source vs restatement, max-abs per stage: fp32 {d32}  fp64 {d64}")
+        print(f"{'':18s} reference-source fp32 vs its own fp64 run (noise floor): {n32}")
+        worst = max(worst, max(d32), max(d64))
+        if a.write:
+            out = os.path.join(ROOT, "tests", "golden", f"ref_source_{name}.npz")
+            np.savez_compressed(out, left=l, right=r, seed=7, calibrated=calib, maxdisplist=np.array(args.maxdisplist),
+                                layers_3d=args.layers_3d, channels_3d=args.channels_3d, growth_rate=np.array(args.growth_rate),
+                                **{f"pred{i}": p.astype(np.float32) for i, p in enumerate(ref32)},
+                                **{f"pred64_{i}": p.astype(np.float64) for i, p in enumerate(ref64)})
+            print("  wrote", out, os.path.getsize(out))
+    print("worst difference reference-source vs restatement:", worst)
+    return 0 if worst == 0.0 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
