@@ -101,11 +101,15 @@ struct WsLayout {
     size_t total_all;
 };
 
+// Feature-map sizes: the stem convolution (submodules.py:118-125: k3 s2 dil2 pad2) gives ceil(H/2); the hourglass halves
+// twice more (check_size guarantees ceil(H/2) % 4 == 0).  H = 8k-1 is therefore as legal as H = 8k.
+static inline int half_up(int v) { return (v + 1) / 2; }
+
 static bool stage_dims(const lws_ctx *h, int s, int H, int W, int &D, int &hh, int &ww)
 {
-    const int div = 8 >> s;
-    hh = H / div;
-    ww = W / div;
+    const int div = 4 >> s;
+    hh = half_up(H) / div;
+    ww = half_up(W) / div;
     D = s == 0 ? h->cfg.maxdisplist[0] : 2 * h->cfg.maxdisplist[s] - 1;
     return true;
 }
@@ -127,11 +131,11 @@ static WsLayout ws_layout(const lws_ctx *h, int B, int H, int W)
     L.cost_raw = L.act_b + al(max_act);
     L.cost_out = L.cost_raw + al(max_cost);
     L.low[0] = L.cost_out + al(max_cost);
-    L.low[1] = L.low[0] + al((size_t)B * (H / 8) * (W / 8));
-    L.low[2] = L.low[1] + al((size_t)B * (H / 4) * (W / 4));
-    L.total = L.low[2] + al((size_t)B * (H / 2) * (W / 2));
-    const size_t N = 2 * (size_t)B, p2 = (size_t)(H / 2) * (W / 2), p4 = (size_t)(H / 4) * (W / 4),
-                 p8 = (size_t)(H / 8) * (W / 8);
+    const int H2 = half_up(H), W2 = half_up(W);
+    const size_t N = 2 * (size_t)B, p2 = (size_t)H2 * W2, p4 = (size_t)(H2 / 2) * (W2 / 2), p8 = (size_t)(H2 / 4) * (W2 / 4);
+    L.low[1] = L.low[0] + al((size_t)B * p8);
+    L.low[2] = L.low[1] + al((size_t)B * p4);
+    L.total = L.low[2] + al((size_t)B * p2);
     size_t o = L.total;
     auto take = [&](size_t n) { size_t r = o; o += al(n); return r; };
     L.fe_a0 = take(N * 4 * p2);
@@ -168,11 +172,12 @@ static int ensure_ws(lws_ctx *h, size_t floats)
 static int check_size(const lws_ctx *h, int B, int H, int W)
 {
     LWS_CHECK_ARG(B >= 1, "batch must be >= 1 (got %d)", B);
-    LWS_CHECK_ARG(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0,
-                  "unsupported input size %dx%d: H and W must be multiples of 8 (ceil(H/2), ceil(W/2) divisible by 4)",
-                  H, W);
-    LWS_CHECK_ARG(W / 8 >= h->cfg.maxdisplist[0], "unsupported input size %dx%d: W/8 = %d must be >= maxdisplist[0] = %d",
-                  H, W, W / 8, h->cfg.maxdisplist[0]);
+    // the hourglass skip-adds (submodules.py:103,182) need ceil(H/2), ceil(W/2) divisible by 4; models.py:72 needs w/8 >= D1
+    LWS_CHECK_ARG(H > 0 && W > 0 && half_up(H) % 4 == 0 && half_up(W) % 4 == 0,
+                  "unsupported input size %dx%d: ceil(H/2) and ceil(W/2) must be divisible by 4", H, W);
+    LWS_CHECK_ARG(half_up(W) / 4 >= h->cfg.maxdisplist[0],
+                  "unsupported input size %dx%d: the 1/8 map is %d wide, must be >= maxdisplist[0] = %d", H, W,
+                  half_up(W) / 4, h->cfg.maxdisplist[0]);
     return LWS_OK;
 }
 
@@ -433,7 +438,7 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
                               hipStream_t tail = nullptr, hipEvent_t *ev = nullptr)
 {
     const Net2d &n = h->net2d;
-    const int N = nA + nB, H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+    const int N = nA + nB, H2 = half_up(H), W2 = half_up(W), H4 = H2 / 2, W4 = W2 / 2, H8 = H2 / 4, W8 = W2 / 4;
     float *ws = h->ws;
     float *a0 = ws + L.fe_a0, *o = ws + L.fe_o, *a2 = ws + L.fe_a2, *o2 = ws + L.fe_o2, *c1 = ws + L.fe_c1,
           *pre = ws + L.fe_pre, *c3 = ws + L.fe_c3;
@@ -483,7 +488,7 @@ static int feature_tail(lws_ctx *h, int N, int H, int W, const WsLayout &L, floa
                         hipStream_t st, hipEvent_t *ev, int part)
 {
     const Net2d &n = h->net2d;
-    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+    const int H2 = half_up(H), W2 = half_up(W), H4 = H2 / 2, W4 = W2 / 2, H8 = H2 / 4, W8 = W2 / 4;
     float *ws = h->ws;
     float *o2 = ws + L.fe_o2, *pre = ws + L.fe_pre, *o3 = ws + L.fe_o3, *cls = ws + L.fe_cls;
     int rc;
@@ -648,7 +653,8 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         // stage 2's map is consumed by stage 3's warp at exactly half resolution; stage 3's by the refinement
         // (measured r01: two launches fewer are worth +0.5 % at batch 1; at batch 8 the heavier consumers cost 1.2 %, so
         // large batches keep the separate k_upsample_add launches)
-        if (defer_up && B <= 2 && (s == 1 || (s == 2 && ds->allow_last))) {
+        // (only at exact 2x geometry: with odd H or W the four taps of a stage-3 pixel are not the 2x2 block it owns)
+        if (defer_up && B <= 2 && H % 2 == 0 && W % 2 == 0 && (s == 1 || (s == 2 && ds->allow_last))) {
             ds->def[s] = true;
             ds->low[s] = low;
             ds->lh[s] = hh;
@@ -995,8 +1001,8 @@ int lws_feature_extraction(lws_handle h, const float *img, int N, int H, int W, 
                            void *stream)
 {
     LWS_CHECK_ARG(h && img && f8 && f4 && f2, "feature_extraction: null pointer");
-    LWS_CHECK_ARG(N >= 1 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0,
-                  "feature_extraction: unsupported size N=%d %dx%d (H, W multiples of 8)", N, H, W);
+    LWS_CHECK_ARG(N >= 1 && H > 0 && W > 0 && half_up(H) % 4 == 0 && half_up(W) % 4 == 0,
+                  "feature_extraction: unsupported size N=%d %dx%d (ceil(H/2), ceil(W/2) divisible by 4)", N, H, W);
     if (!h->finalized || !h->have_2d) {
         set_error("feature_extraction: the 2D network tensors were not all set before lws_finalize");
         return LWS_ERR_STATE;
@@ -1011,7 +1017,7 @@ int lws_feature_extraction(lws_handle h, const float *img, int N, int H, int W, 
 int lws_refine(lws_handle h, const float *left, const float *pred3, int B, int H, int W, float *pred4, void *stream)
 {
     LWS_CHECK_ARG(h && left && pred3 && pred4, "refine: null pointer");
-    LWS_CHECK_ARG(B >= 1 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "refine: unsupported size B=%d %dx%d", B, H, W);
+    LWS_CHECK_ARG(B >= 1 && H > 0 && W > 0, "refine: unsupported size B=%d %dx%d", B, H, W);
     if (!h->finalized || !h->have_2d) {
         set_error("refine: the 2D network tensors were not all set before lws_finalize");
         return LWS_ERR_STATE;
@@ -1074,8 +1080,7 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     float *f8 = h->ws + L.fe_f8, *f4 = h->ws + L.fe_f4, *f2 = h->ws + L.fe_f2;
     rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st, h->side, h->ev_feat);   // models.py:110-111
     if (rc) return rc;
-    const size_t n8 = (size_t)B * 16 * (H / 8) * (W / 8), n4 = (size_t)B * 16 * (H / 4) * (W / 4),
-                 n2 = (size_t)B * 8 * (H / 2) * (W / 2);
+    const size_t n2 = (size_t)B * 8 * half_up(H) * half_up(W), n4 = n2 / 2, n8 = n2 / 8;   // 8 / 16 / 16 channels
     const float *fl[3] = {f8, f4, f2};
     const float *fr[3] = {f8 + n8, f4 + n4, f2 + n2};
     // The rest of the feature extractor (f4 for stage 2, f2 for stage 3) is launched on the side stream right after

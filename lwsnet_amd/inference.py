@@ -42,22 +42,25 @@ def inference(model, left_imgs, right_imgs, args, log):
     import torch
     from . import imageio as io
     written = []
+    warm = False
     for li, ri in zip(left_imgs, right_imgs):
         left = io.crop_bottom_right(io.load_rgb(li))
         right = io.crop_bottom_right(io.load_rgb(ri))
         if left is None or right is None:                               # :96-97
             continue
         l_in, r_in = io.to_input(left)[None], io.to_input(right)[None]
-        model(l_in, r_in)                                               # warm-up (the reference times its first call)
-        torch.cuda.synchronize()
+        if not warm:                                                    # one warm-up in all (the reference times its first call)
+            model(l_in, r_in)
+            warm = True
+        torch.cuda.synchronize(model.device)
         t0 = time.time()
         outputs = model(l_in, r_in)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(model.device)
         cost = time.time() - t0
         ss = "Inference 4 stages cost = {:.3f} sec, FPS = {:.1f}".format(cost, 1 / cost)
         color = None
         for stage in range(4):
-            disp = outputs[stage].squeeze(0).squeeze(0).cpu().numpy()
+            disp = outputs[stage].squeeze(axis=[0, 1]).numpy()          # :114 (the uint8 cast is inside disparity_to_color)
             color = io.disparity_to_color(disp)
             if args.left_img:                                           # :117-122
                 path = os.path.join(os.path.dirname(args.left_img), str(stage + 1) + ".png")
@@ -83,6 +86,7 @@ def main(argv=None):
     from .checkpoint import load_state_dict
     from .models import LWSNet
     from .weights import make_state_dict
+    torch.cuda.set_device(args.gpu_id)                                  # inference.py:38
     model = LWSNet(args, device=torch.device("cuda", args.gpu_id))
     if args.synthetic_weights:
         model.set_state_dict(make_state_dict(7, args))

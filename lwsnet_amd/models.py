@@ -19,6 +19,63 @@ from .synth import check_size
 from .weights import state_dict_spec
 
 
+class DisparityTensor(torch.Tensor):
+    """What ``model(left, right)`` returns per stage: a device-resident ``torch.Tensor`` that also answers the Paddle
+    spellings the reference's callers use on the outputs -- ``outputs[stage].squeeze(axis=[0, 1]).numpy()``
+    (/root/reference/inference.py:114), ``.unsqueeze(axis=...)``, ``.numpy()`` on a device tensor (train.py:188).
+    ``.numpy()`` is the device-to-host copy and therefore the synchronisation point, exactly as with a Paddle GPU tensor.
+    Everything else is plain torch; ``__dlpack__`` (inherited) hands the buffer to any other framework without a copy."""
+
+    @staticmethod
+    def wrap(t):
+        return t.as_subclass(DisparityTensor)
+
+    def squeeze(self, dim=None, axis=None):
+        ax = axis if axis is not None else dim
+        if ax is None:
+            return torch.Tensor.squeeze(self)
+        t = self
+        for a in sorted([int(v) % self.dim() for v in (ax if isinstance(ax, (list, tuple)) else [ax])], reverse=True):
+            t = torch.Tensor.squeeze(t, a)
+        return t
+
+    def unsqueeze(self, dim=None, axis=None):
+        ax = axis if axis is not None else dim
+        t = self
+        for a in (ax if isinstance(ax, (list, tuple)) else [ax]):
+            t = torch.Tensor.unsqueeze(t, int(a))
+        return t
+
+    def numpy(self):
+        return torch.Tensor.numpy(self.detach().as_subclass(torch.Tensor).cpu())
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+
+def as_input(x, name, device=None):
+    """Accepts what the reference's callers hand to ``model(left, right)``: a Paddle tensor is anything that exports
+    DLPack (device buffers are taken without a copy) or answers ``.numpy()`` / ``__array__`` (inference.py:102-103
+    builds its inputs with paddle.vision transforms + ``.unsqueeze(axis=0)``); numpy arrays and torch tensors too.
+    Returns a contiguous float32 ``[B,3,H,W]`` torch tensor on `device`."""
+    if isinstance(x, torch.Tensor):
+        t = x
+    elif isinstance(x, np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    elif hasattr(x, "__dlpack__") and hasattr(x, "__dlpack_device__") and x.__dlpack_device__()[0] != 1:
+        t = torch.from_dlpack(x)                       # a device tensor of another framework (kDLCPU == 1 goes below)
+    elif callable(getattr(x, "numpy", None)):
+        t = torch.from_numpy(np.ascontiguousarray(x.numpy(), dtype=np.float32))
+    elif hasattr(x, "__array__"):
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32))
+    else:
+        raise TypeError(f"{name} must be a tensor (torch / DLPack / .numpy() / __array__) or a numpy array, got {type(x).__name__}")
+    if t.dim() != 4 or t.shape[1] != 3:
+        raise ValueError(f"{name} must be [B,3,H,W]; got {tuple(t.shape)}")
+    return t.detach().as_subclass(torch.Tensor).to(device=device, dtype=torch.float32).contiguous()
+
+
 class LWSNet:
     def __init__(self, args, device=None):
         self.maxdisplist = [int(v) for v in args.maxdisplist]      # models.py:11-14
@@ -113,13 +170,7 @@ class LWSNet:
 
     # ---- forward -------------------------------------------------------------------------------
     def _input(self, x, name):
-        if isinstance(x, np.ndarray):
-            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
-        if not isinstance(x, torch.Tensor):
-            raise TypeError(f"{name} must be a torch tensor or numpy array")
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise ValueError(f"{name} must be [B,3,H,W]; got {tuple(x.shape)}")
-        return x.to(device=self.device, dtype=torch.float32).contiguous()
+        return as_input(x, name, self.device)
 
     def forward(self, left_input, right_input):
         if self.device is None:
@@ -133,6 +184,6 @@ class LWSNet:
         B, _, H, W = left.shape
         check_size(H, W, self.maxdisplist[0])
         with torch.cuda.device(self.device):
-            return ops.forward(self._h, left, right)                                          # models.py:106-164
+            return [DisparityTensor.wrap(p) for p in ops.forward(self._h, left, right)]      # models.py:106-164
 
     __call__ = forward

@@ -106,7 +106,8 @@ def disparity_stages(handle, feats_l, feats_r, H, W):
     if len(fl) != 3 or len(fr) != 3:
         raise ValueError("feats_l / feats_r must hold the three feature maps (1/8, 1/4, 1/2)")
     B = fl[0].shape[0]
-    want = [(B, 16, H // 8, W // 8), (B, 16, H // 4, W // 4), (B, 8, H // 2, W // 2)]
+    h2, w2 = (H + 1) // 2, (W + 1) // 2                 # the stem convolution gives ceil(H/2) (submodules.py:118-125)
+    want = [(B, 16, h2 // 4, w2 // 4), (B, 16, h2 // 2, w2 // 2), (B, 8, h2, w2)]
     for i in range(3):
         if tuple(fl[i].shape) != want[i] or tuple(fr[i].shape) != want[i]:
             raise ValueError(f"stage {i + 1} features must be {want[i]}; got {tuple(fl[i].shape)} / {tuple(fr[i].shape)}")
@@ -126,9 +127,10 @@ def feature_extraction(handle, img):
     if x.dim() != 4 or x.shape[1] != 3:
         raise ValueError(f"img must be [N,3,H,W]; got {tuple(x.shape)}")
     N, _, H, W = x.shape
-    f8 = torch.empty((N, 16, H // 8, W // 8), device=x.device, dtype=torch.float32)
-    f4 = torch.empty((N, 16, H // 4, W // 4), device=x.device, dtype=torch.float32)
-    f2 = torch.empty((N, 8, H // 2, W // 2), device=x.device, dtype=torch.float32)
+    h2, w2 = (H + 1) // 2, (W + 1) // 2
+    f8 = torch.empty((N, 16, h2 // 4, w2 // 4), device=x.device, dtype=torch.float32)
+    f4 = torch.empty((N, 16, h2 // 2, w2 // 2), device=x.device, dtype=torch.float32)
+    f2 = torch.empty((N, 8, h2, w2), device=x.device, dtype=torch.float32)
     lib = _lib.load()
     with torch.cuda.device(x.device):
         _lib.check(lib.lws_feature_extraction(handle, _ptr(x), N, H, W, _ptr(f8), _ptr(f4), _ptr(f2), _stream()),

@@ -17,15 +17,14 @@ IMAGENET_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
 def check_size(H, W, maxdisp0=24):
     """Sizes the network accepts: the 2D hourglass skip-adds
     (/root/reference/models/submodules.py:103,182) need ceil(H/2), ceil(W/2)
-    divisible by 4, and the stage-1 volume (models/models.py:72) needs
-    W/8 > maxdisplist[0] - 1."""
+    divisible by 4 (so H = 8k or 8k-1: the stem convolution, submodules.py:118-125,
+    gives ceil(H/2)), and the stage-1 volume (models/models.py:72) needs the 1/8 map
+    to be at least maxdisplist[0] wide."""
     h2, w2 = (H + 1) // 2, (W + 1) // 2
     if H <= 0 or W <= 0 or h2 % 4 or w2 % 4:
         raise ValueError(f"unsupported input size {H}x{W}: ceil(H/2) and ceil(W/2) must be divisible by 4")
-    if H % 2 or W % 2:
-        raise ValueError(f"unsupported input size {H}x{W}: H and W must be even")
-    if W // 8 < maxdisp0:
-        raise ValueError(f"unsupported input size {H}x{W}: W/8={W // 8} must be >= maxdisplist[0]={maxdisp0}")
+    if w2 // 4 < maxdisp0:
+        raise ValueError(f"unsupported input size {H}x{W}: the 1/8 map is {w2 // 4} wide, must be >= maxdisplist[0]={maxdisp0}")
 
 
 def _box_blur(a, k=9):

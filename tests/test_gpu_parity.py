@@ -321,6 +321,32 @@ def test_forward_small_and_ragged_sizes(dev, model, H, W):
         assert_bits(pred[s], want[s], f"{H}x{W} stage {s + 1}")
 
 
+@pytest.mark.parametrize("H,W", [(63, 255), (64, 255), (63, 256), (39, 199), (367, 1231)])
+def test_forward_odd_sizes(dev, model, H, W):
+    """H, W = 8k-1 are legal for the reference: its stem convolution (submodules.py:118-125, k3 s2 dil2 pad2) gives
+    ceil(H/2), so 367x1231 runs there (the 375x1242 KITTI frame minus 8x11).  Every resize then has a non-integer
+    ratio and the deferred-map plan is off.  Bit-exact against the C oracle, which itself sits on the reference source's
+    noise floor at 63x255 (tests/test_oracle_cpu.py::test_c_oracle_odd_size_matches_reference_source)."""
+    from oracle import c_oracle as C
+    left, right = make_batch(2 if H < 100 else 1, H, W, 17)
+    pred = model(left, right)
+    want = C.forward(left, right, model.state_dict())
+    for s in range(4):
+        assert tuple(pred[s].shape) == (left.shape[0], 1, H, W)
+        assert_bits(pred[s], want[s], f"{H}x{W} stage {s + 1}")
+
+
+def test_forward_odd_size_vs_reference_source(dev, model):
+    """63x255 against the stage maps the reference's own source produced (tests/golden/ref_source_e2e_odd_63x255.npz):
+    no further from its float64 run than 1.5x its float32 run is."""
+    g = golden("ref_source_e2e_odd_63x255.npz")
+    pred = model(g["left"], g["right"])
+    for s in range(4):
+        floor = float(np.abs(g[f"pred{s}"].astype(np.float64) - g[f"pred64_{s}"]).max())
+        mine = float(np.abs(pred[s].cpu().numpy().astype(np.float64) - g[f"pred64_{s}"]).max())
+        assert mine <= 1.5 * floor + 1e-4, f"stage {s + 1}: {mine:.3e} vs {floor:.3e}"
+
+
 @pytest.mark.parametrize("kind", ["zeros", "constant", "huge"])
 def test_forward_degenerate_inputs(dev, model, kind):
     """All-zero and constant images (every hypothesis has the same cost: the soft-argmin is an exact tie) and inputs
@@ -402,6 +428,8 @@ def test_forward_rejects_bad_sizes(dev, model):
     with pytest.raises(ValueError):
         model(z, z)
     with pytest.raises(ValueError):
+        model(np.zeros((1, 3, 62, 256), np.float32), np.zeros((1, 3, 62, 256), np.float32))     # ceil(62/2) = 31
+    with pytest.raises(ValueError):
         model(np.zeros((1, 3, 64, 128), np.float32), np.zeros((1, 3, 64, 128), np.float32))   # W/8 < 24
 
 
@@ -434,6 +462,39 @@ def test_inference_cli_writes_four_stage_maps(dev, hip_lib, tmp_path):
     assert np.array_equal(np.asarray(Image.open(written[3])), want)
     with pytest.raises(SystemExit):                    # inference.py:41-43: missing checkpoint
         inference.main(["--left_img", str(tmp_path / "left_test.png"), "--model", str(tmp_path / "missing.pdparams")])
+
+
+def test_dropin_inference_expression_sequence(dev, model):
+    """The statements of /root/reference/inference.py:102-103,108,114 with only the model class swapped: inputs are
+    Paddle-like tensors (duck type: list `.shape`, `.unsqueeze(axis=0)`, `.numpy()`), outputs are consumed as
+    `outputs[stage].squeeze(axis=[0, 1]).numpy().astype(np.uint8)`."""
+    from test_host_cpu import FakePaddleTensor
+    from lwsnet_amd.synth import make_pair
+    l, r, _ = make_pair(64, 256, 2)
+    left_input = FakePaddleTensor(l).unsqueeze(axis=0)            # :102
+    right_input = FakePaddleTensor(r).unsqueeze(axis=0)           # :103
+    outputs = model(left_input, right_input)                      # :108
+    ref = model(l[None], r[None])
+    assert isinstance(outputs, list) and len(outputs) == 4
+    for stage in range(4):
+        assert list(outputs[stage].shape) == [1, 1, 64, 256]
+        outputs[stage] = outputs[stage].squeeze(axis=[0, 1]).numpy().astype(np.uint8)      # :114
+        assert outputs[stage].shape == (64, 256) and outputs[stage].dtype == np.uint8
+        assert np.array_equal(outputs[stage], ref[stage][0, 0].cpu().numpy().astype(np.uint8))
+    # a device tensor of another framework comes in through DLPack without a host round trip
+    class DlpackOnly:
+        def __init__(self, t):
+            self._t = t
+
+        def __dlpack__(self, stream=None):
+            return self._t.__dlpack__()
+
+        def __dlpack_device__(self):
+            return self._t.__dlpack_device__()
+
+    lt, rt = cu(l[None], dev), cu(r[None], dev)
+    out2 = model(DlpackOnly(lt), DlpackOnly(rt))
+    assert all(torch.equal(a, b) for a, b in zip(out2, ref))
 
 
 # ------------------------------------------------------------------ the other BASELINE configs

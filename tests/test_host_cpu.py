@@ -62,3 +62,60 @@ def test_metrics_match_reference_formulas():
     d = np.array([[14.0, 104.0, 5.0, 0.0, 52.0]])
     assert metrics.error_3px(d, gt) == pytest.approx(1.0 / 3.0)
     assert metrics.end_point_error(d, gt) == pytest.approx((4 + 4 + 5 + 2) / 4.0)
+
+
+# ---- drop-in boundary: the expressions /root/reference/inference.py:102-103,108,114 evaluate -----------------------
+class FakePaddleTensor:
+    """Duck type of a Paddle 2.0 tensor as the reference's caller builds it (paddle.vision ToTensor/Normalize output):
+    `.shape` is a list, `.unsqueeze(axis=0)`, `.numpy()`; it is neither a numpy array nor a torch tensor."""
+
+    def __init__(self, a):
+        self._a = np.asarray(a, dtype=np.float32)
+
+    @property
+    def shape(self):
+        return list(self._a.shape)
+
+    def unsqueeze(self, axis):
+        return FakePaddleTensor(np.expand_dims(self._a, axis))
+
+    def numpy(self):
+        return self._a
+
+
+def test_inputs_accept_paddle_like_tensors():
+    import torch
+    from lwsnet_amd.models import as_input
+    img = np.random.default_rng(0).standard_normal((3, 16, 32)).astype(np.float32)
+    left_input = FakePaddleTensor(img).unsqueeze(axis=0)                     # inference.py:102
+    t = as_input(left_input, "left_input")
+    assert isinstance(t, torch.Tensor) and tuple(t.shape) == (1, 3, 16, 32) and t.dtype == torch.float32
+    assert np.array_equal(t.numpy(), img[None])
+
+    class ArrayOnly:                                                         # __array__ protocol only
+        def __array__(self, dtype=None, copy=None):
+            return img[None]
+
+    assert np.array_equal(as_input(ArrayOnly(), "x").numpy(), img[None])
+    assert np.array_equal(as_input(torch.from_numpy(img[None]).double(), "x").numpy(), img[None])
+    with pytest.raises(TypeError):
+        as_input("left.png", "left_input")
+    with pytest.raises(ValueError):
+        as_input(FakePaddleTensor(img), "left_input")                        # forgot the batch axis
+
+
+def test_outputs_answer_the_callers_paddle_spellings():
+    import torch
+    from lwsnet_amd.models import DisparityTensor
+    d = np.random.default_rng(1).random((1, 1, 6, 10)).astype(np.float32) * 190
+    outputs = [DisparityTensor.wrap(torch.from_numpy(d.copy())) for _ in range(4)]
+    for stage in range(4):
+        outputs[stage] = outputs[stage].squeeze(axis=[0, 1]).numpy().astype(np.uint8)      # inference.py:114
+        assert outputs[stage].shape == (6, 10) and np.array_equal(outputs[stage], d[0, 0].astype(np.uint8))
+    o = DisparityTensor.wrap(torch.from_numpy(d.copy()))
+    assert tuple(o.squeeze(1).shape) == (1, 6, 10)                            # paddle.squeeze(outputs[stage], 1) (train.py:188)
+    assert tuple(o.squeeze().shape) == (6, 10) and tuple(o.squeeze(axis=0).unsqueeze(axis=[0, 1]).shape) == (1, 1, 1, 6, 10)
+    assert o.shape[2] == 6 and list(o.shape) == [1, 1, 6, 10]
+    assert np.array_equal(np.asarray(o), d) and np.array_equal(o[0, 0].numpy(), d[0, 0])
+    assert isinstance(o + 1.0, torch.Tensor)                                  # still a torch tensor for everything else
+    assert np.array_equal(torch.from_dlpack(o).numpy(), d)                    # zero-copy hand-over to other frameworks
