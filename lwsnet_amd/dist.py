@@ -19,9 +19,12 @@ def env_rank():
 
 
 def init_from_env(backend=None):
-    """Initialise the default process group from torchrun's environment (no-op for world size 1)."""
+    """Initialise the default process group from torchrun's environment.  Without that environment (plain
+    `python bench.py`) this is a no-op; under torchrun a world of ONE is initialised too, so that a single GPU runs the
+    same RCCL code path (communicator set-up, gather, barrier) the N-GPU job runs."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if launched and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -45,7 +48,7 @@ def gather_pairs(local, counts=None, dst=0, group=None):
     """Gathers per-rank disparity maps [b_r,1,H,W] to `dst` (concatenated in rank order); other ranks get None.
 
     Equal shards use one `gather`; ragged shards are padded to the largest shard first."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if counts is None:
@@ -63,6 +66,13 @@ def gather_pairs(local, counts=None, dst=0, group=None):
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
 
 
+def gather_async(local, bufs, dst=0, group=None):
+    """The ONE collective of the path as bench.py issues it per step: equal shards, buffers pre-allocated on `dst`
+    (`bufs`: list of world tensors there, None elsewhere), asynchronous -- RCCL runs it on its own stream behind this
+    step's kernels so it overlaps the next step.  Returns the work handle (wait() before reading `bufs`)."""
+    return dist.gather(local.contiguous(), bufs if dist.get_rank(group) == dst else None, dst=dst, group=group, async_op=True)
+
+
 def sharded_forward(model_fn, left, right, dst=0):
     """Runs `model_fn(left_shard, right_shard) -> [4 x [b,1,H,W]]` on this rank's shard of the global batch
     and gathers the stage-4 maps on `dst`.  `left`/`right` are the GLOBAL batch (every rank holds or can
@@ -70,6 +80,10 @@ def sharded_forward(model_fn, left, right, dst=0):
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     B = left.shape[0]
+    if B < world:
+        # some rank would get an empty shard: lws_forward needs B >= 1, and a rank that raises while the others sit
+        # in the gather hangs the job -- so every rank raises the same error up front
+        raise ValueError(f"global batch {B} is smaller than the world size {world}: every rank needs at least one pair")
     lo, hi = shard_range(B, rank, world)
     preds = model_fn(left[lo:hi], right[lo:hi])
     counts = [shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]

@@ -1,0 +1,47 @@
+"""RCCL on one GPU (SURVEY.md sections 4 / 8e): the multi-GPU path is pure batch sharding plus ONE gather, so a world of
+one exercises every RCCL call the N-GPU job makes.  Both tests run in child processes (they initialise a communicator)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def test_nccl_world1_sharded_forward_bitwise(hip_lib):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_world1_child.py"), str(_port())],
+                       capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert "OK nccl world_size=1" in p.stdout
+
+
+def test_bench_under_torchrun_world1(hip_lib):
+    """bench.py as the driver launches it for N > 1, with N = 1: communicator, per-step async gather of the stage-4
+    maps on device memory, barrier-bracketed clock, MAX all-reduce -- one JSON line from rank 0."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["collective"]["backend"] == "nccl"
+    assert d["collective"]["rank0_slot_equals_local"] is True

@@ -24,7 +24,9 @@ for name in ("fetch", "write"):
         e = out.setdefault(f"{k} grid={g}", {})
         e[name.upper() + "_SIZE_KB_avg"] = round(sum(v) / len(v), 2)
         e["launches"] = len(v)
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), `python3 bench.py --steps 5 --warmup 2 "
+import hashlib
+sha = {n: hashlib.sha256(open(f"lwsnet_amd/csrc/{n}", "rb").read()).hexdigest() for n in ("lws_conv3d.hip", "lws_conv2d.hip")}
+json.dump({"kernel_source_sha256": sha, "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), `python3 bench.py --steps 5 --warmup 2 "
            "--no-cpu-baseline`, B=1 256x512. Raw counter values in KB per launch; on gfx950 FETCH_SIZE under-reports wide "
            "(16 B/lane) streaming reads by 2x (MI355X_MICROARCH.md, HBM section): corrected HBM-side bytes = 2*FETCH + WRITE.",
            "kernels": out}, open(f"{dst}/pmc_fetch_write_b1_256x512.json", "w"), indent=1)
