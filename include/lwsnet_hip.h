@@ -129,6 +129,8 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "fuse_shift"     1 (default) = stage-1 volume built inside the first Conv3D launch
  *   "fuse_first"     1 (default) = refinement1_disp's 1 -> 32 convolution inside its first depthwise block
  *   "defer_upsample" 1 (default) = at batches <= 2 the consumers evaluate the stage-2/3 maps
+ *   "fuse_dws"       0 (default); 1 = consecutive depthwise-separable blocks of the refinement pairwise in one launch
+ *                    (k_ref_dws2: 7 instead of 12 launches; measured r02: slower end to end at batch 1 and 8)
  * Unknown names and out-of-range values return LWS_ERR_INVALID. */
 int lws_set_option(lws_handle h, const char *name, int value);
 int lws_get_option(lws_handle h, const char *name, int *value);

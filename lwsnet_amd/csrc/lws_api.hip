@@ -525,6 +525,14 @@ static int refine_left(lws_ctx *h, const float *left, int B, int H, int W, const
     const Net2d &n = h->net2d;
     float *ra = h->ws + L.r_a, *rc_ = h->ws + L.r_c;
     int rc;
+    if (h->opt.fuse_dws && ref_dws_pair_can_fuse(n.r1[0][0], n.r1[0][1]) && ref_dws_pair_can_fuse(n.r1[0][2], n.r1[0][3])) {
+        // blocks (dil 2, 4) and (dil 8, 16) pairwise in one launch each: 3 launches instead of 5, result in r_a
+        LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(left, 3, n.r1_first[0], rc_, B, H, W, st));
+        float *rb = h->ws + L.r_b;      // free until refine_rest, which runs after this branch has joined
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws_pair(n.r1[0][0], n.r1[0][1], rc_, rb, B, H, W, st));
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws_pair(n.r1[0][2], n.r1[0][3], rb, ra, B, H, W, st));
+        return LWS_OK;
+    }
     LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(left, 3, n.r1_first[0], ra, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][0], ra, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][1], rc_, ra, B, H, W, st));
@@ -567,14 +575,26 @@ static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLa
         LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(pred3, 1, n.r1_first[1], rb, B, H, W, st));
         LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][0], rb, rc_, B, H, W, st));
     }
-    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][1], rc_, rb, B, H, W, st));
-    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][2], rb, rc_, B, H, W, st));
-    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][3], rc_, rb, B, H, W, st));
+    // refinement1_disp blocks 2..4 (dil 4, 8, 16; block 1 ran above): rc_ -> ... -> rb
+    if (h->opt.fuse_dws && ref_dws_pair_can_fuse(n.r1[1][1], n.r1[1][2])) {
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws_pair(n.r1[1][1], n.r1[1][2], rc_, rb, B, H, W, st));     // dil 4, 8
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][3], rb, rc_, B, H, W, st));                       // dil 16
+        std::swap(rb, rc_);
+    } else {
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][1], rc_, rb, B, H, W, st));
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][2], rb, rc_, B, H, W, st));
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][3], rc_, rb, B, H, W, st));
+    }
     LWS_RF(LWS_KC_REF_CONV64, launch_ref_conv64(n.r2_first, ra, rb, rc_, B, H, W, st));
-    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[0], rc_, ra, B, H, W, st));
-    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[1], ra, rc_, B, H, W, st));
-    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[2], rc_, ra, B, H, W, st));
-    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[3], ra, rc_, B, H, W, st));
+    if (h->opt.fuse_dws && ref_dws_pair_can_fuse(n.r2[0], n.r2[1]) && ref_dws_pair_can_fuse(n.r2[2], n.r2[3])) {
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws_pair(n.r2[0], n.r2[1], rc_, ra, B, H, W, st));             // dil 8, 4
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws_pair(n.r2[2], n.r2[3], ra, rc_, B, H, W, st));             // dil 2, 1
+    } else {
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[0], rc_, ra, B, H, W, st));
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[1], ra, rc_, B, H, W, st));
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[2], rc_, ra, B, H, W, st));
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[3], ra, rc_, B, H, W, st));
+    }
     LWS_RF(LWS_KC_REF_LAST, launch_ref_last(rc_, n.r2_last, pred3, pred4, B, H, W, st));
     return LWS_OK;
 }
@@ -644,9 +664,20 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         }
         if (!fused) {
             // soft-argmin + rescale + upsample (+ previous stage) in one launch                             :142-148
-            ProfScope p(h, LWS_KC_SOFTARGMIN, st);
-            rc = launch_softargmin_upsample(cost, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], nullptr, B, D, hh, ww,
-                                            H, W, start, st);
+            if (H % hh == 0 && W % ww == 0) {
+                ProfScope p(h, LWS_KC_SOFTARGMIN, st);
+                rc = launch_softargmin_upsample(cost, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], nullptr, B, D, hh, ww,
+                                                H, W, start, st);
+            } else {
+                // H or W = 8k-1: the resize ratio is not an integer, which the fused kernel's tile -> block map needs
+                {
+                    ProfScope p(h, LWS_KC_SOFTARGMIN, st);
+                    rc = launch_softargmin(cost, low, B, D, hh, ww, start, st);
+                }
+                if (rc) return rc;
+                ProfScope p(h, LWS_KC_UPSAMPLE, st);
+                rc = launch_upsample_add(low, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], B, hh, ww, H, W, st);
+            }
             if (rc) return rc;
             continue;
         }
@@ -720,7 +751,8 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"split_heads", &h->opt.split_heads},
                                                      {"fuse_shift", &h->opt.fuse_shift},
                                                      {"fuse_first", &h->opt.fuse_first},
-                                                     {"defer_upsample", &h->opt.defer_upsample}};
+                                                     {"defer_upsample", &h->opt.defer_upsample},
+                                                     {"fuse_dws", &h->opt.fuse_dws}};
     for (auto &e : tab)
         if (strcmp(e.name, name) == 0) return e.slot;
     return nullptr;

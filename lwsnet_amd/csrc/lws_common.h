@@ -56,7 +56,7 @@ static inline int use_wt_stores(size_t out_bytes) { return out_bytes <= ((size_t
 // Diagnostic builds only (LWS_EXTRA_FLAGS="-DLWS_STAMPS=<kernel id>"; tools/stamps.py): every workgroup of the selected
 // kernel stores s_memtime stamps of its phases in a per-translation-unit buffer.  The shipped library compiles
 // LWS_STAMPK to nothing.  Kernel ids: 1 mid16, 2 mid8, 3 conv3d_last, 4 conv3d_first, 5 ref_dws, 6 ref_conv64,
-// 7 conv2d_nchw, 8 ref_first, 9 ref_last, 10 volume_warp, 11 volume_shift, 12 softargmin_upsample, 13..16 conv2d_pair (dres0, dres1, conv1+2, conv3+4).
+// 7 conv2d_nchw, 8 ref_first, 9 ref_last, 10 volume_warp, 11 volume_shift, 12 softargmin_upsample, 13..16 conv2d_pair (dres0, dres1, conv1+2, conv3+4), 17 ref_dws2.
 #ifdef LWS_STAMPS
 #define LWS_DEFINE_STAMPS(tu)                                                                                      \
     __device__ unsigned long long g_stamps_##tu[4096 * 8];                                                         \
@@ -145,6 +145,7 @@ struct lws_ctx {
         int fuse_shift = 1;        // stage-1 volume inside the first Conv3D launch
         int fuse_first = 1;        // refinement1_disp's 1 -> 32 convolution inside its first depthwise block
         int defer_upsample = 1;    // batches <= 2: consumers evaluate the stage-2/3 maps (no k_upsample_add launches)
+        int fuse_dws = 0;          // consecutive depthwise-separable blocks of the refinement pairwise in one launch (measured slower, r02)
     } opt;
     unsigned prof_mask = 0;                  // kernel classes being timed in the current call
     unsigned prof_mask_cfg = 0;              // ... as configured by lws_profile_enable
@@ -209,6 +210,8 @@ int launch_conv2d_pair(const Conv2dLayer &a, const Conv2dLayer &b, const float *
                        int H, int W, hipStream_t st, const float *in2 = nullptr, int n1 = 0);
 int launch_ref_first(const float *in, int cin, const float *w, float *out, int B, int H, int W, hipStream_t st);
 int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, int W, hipStream_t st);
+bool ref_dws_pair_can_fuse(const RefDws &a, const RefDws &b);
+int launch_ref_dws_pair(const RefDws &a, const RefDws &b, const float *in, float *out, int B, int H, int W, hipStream_t st);
 bool ref_first_dws_can_fuse(const RefDws &l, int cin);
 int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst, float *out, int B, int H, int W,
                          hipStream_t st, const float *plow = nullptr, int ph = 0, int pw = 0, float *pmat = nullptr);

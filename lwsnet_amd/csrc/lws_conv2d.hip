@@ -826,6 +826,238 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
 }
 
 // =============================================================================================
+// TWO consecutive depthwise-separable blocks in one launch (k_ref_dws2): block A (dilation a) then block B (dilation b)
+// with M = min(a, b) dividing both -- the pairs of the refinement are (2,4), (4,8), (8,16) (refinement1,
+// submodules.py:298) and (8,4), (2,1) (refinement2, :316).  On the phase grid of modulus M both blocks are dense-ish
+// 3x3 problems with dilations DA = a/M and DB = b/M in {1, 2}; a workgroup owns RT_Y x RT_X phase pixels of B's output,
+// computes A on the (RT_Y + 2 DB) x (RT_X + 2 DB) region B's taps read (recomputing A's halo instead of a 16.8 MB
+// round trip through HBM/L2 per image and one more launch) and keeps it in LDS:
+//   1. stage A's input region (R0: 14 x 22 phase pixels for both pairings) with BN_A + ReLU, zeros outside the image;
+//   2. depthwise A on VALU over region R1 -> LDS in MFMA B-operand order;
+//   3. pointwise A on fp32 MFMA over R1 as a flat list of 16-pixel tiles; epilogue = BN_B + ReLU (zeros outside the
+//      image: B's padding is applied after its BatchNorm + ReLU, as in the unfused launch) -> LDS image of B's input,
+//      planar by 4-channel group (a lane's 4 accumulator registers are exactly one group), aliased onto the R0 image;
+//   4. depthwise B over the tile; 5. pointwise B on MFMA; store the raw result.
+// Every value is produced by the same fmaf / MFMA chains as two k_ref_dws launches: bit-identical.
+// LDS 70.7 KB (2 workgroups per CU); reads 2.4 lines per output pixel instead of 2 x 1.56 + the intermediate's write + read.
+// =============================================================================================
+template <int DA, int DB>
+struct Dws2Cfg {
+    static constexpr int R1Y = RT_Y + 2 * DB, R1X = RT_X + 2 * DB, N1 = R1Y * R1X;   // block A's output region
+    static constexpr int R0Y = R1Y + 2 * DA, R0X = R1X + 2 * DA, N0 = R0Y * R0X;     // block A's input region
+    static constexpr int NT1 = (N1 + 15) / 16, TPW = (NT1 + 3) / 4;                 // pointwise-A pixel tiles (per wave)
+    // plane strides in float4 with (4 * stride) % 64 an odd multiple of 8 dwords: the 8 planes of a pixel hit 64 banks
+    static constexpr int pad(int n) { return n + ((2 - n % 4) + 4) % 4; }
+    static constexpr int S0 = pad(N0), S1 = pad(NT1 * 16);
+    static constexpr int SITER = (N0 * 8 + 255) / 256, DITER = (N1 + 31) / 32;
+    static constexpr int LDS_BYTES = 8 * (S0 + S1) * 16;
+    static_assert(S0 >= N1 && S1 >= RT_Y * RT_X, "aliased images must fit");
+};
+
+template <int DA, int DB>
+__global__ __launch_bounds__(256) void k_ref_dws2(const float *__restrict__ in,                    // [B,H,W,32]
+                                                  const float *__restrict__ bnA_s, const float *__restrict__ bnA_t,
+                                                  const float *__restrict__ dwA, const float4 *__restrict__ pwA,
+                                                  const float *__restrict__ bnB_s, const float *__restrict__ bnB_t,
+                                                  const float *__restrict__ dwB, const float4 *__restrict__ pwB,
+                                                  float *__restrict__ out, int H, int W, int M, int nbx, int nby, int wt)
+{
+    using Cfg = Dws2Cfg<DA, DB>;
+    constexpr int R1X = Cfg::R1X, N1 = Cfg::N1, R0X = Cfg::R0X, N0 = Cfg::N0, S0 = Cfg::S0, S1 = Cfg::S1;
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    float4 *sA = lds4;                 // [8][S0]: R0 image (BN_A+ReLU'd input), later the R1 image (B's input)
+    float4 *sB = lds4 + 8 * S0;        // [8][S1]: depthwise results in B-operand order (A over R1, later B over the tile)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const RefTile t = ref_tile(M, nbx, nby);
+    const int c4 = tid & 7;
+    LWS_STAMPK(17, 0);
+
+    // ---- 1. stage R0: item = (pixel hp, 4-channel group c4); all loads in flight before the first LDS write ----
+    {
+        const float4 s4 = *reinterpret_cast<const float4 *>(bnA_s + c4 * 4);
+        const float4 t4 = *reinterpret_cast<const float4 *>(bnA_t + c4 * 4);
+        const float *inb = in + (int64_t)t.b * H * W * 32;
+        float4 c[Cfg::SITER];
+        bool okv[Cfg::SITER];
+#pragma unroll
+        for (int i = 0; i < Cfg::SITER; ++i) {
+            const int hp = (tid >> 3) + 32 * i;
+            const int hy = hp / R0X, hx = hp - hy * R0X;
+            const int gy = t.Y0 + (hy - DA - DB) * M, gx = t.X0 + (hx - DA - DB) * M;
+            okv[i] = hp < N0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int off = okv[i] ? (gy * W + gx) * 32 + c4 * 4 : 0;      // one image < 2^31 floats
+            c[i] = *reinterpret_cast<const float4 *>(inb + off);
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::SITER; ++i) {
+            const int hp = (tid >> 3) + 32 * i;
+            float4 v = make_float4(bn_relu2(c[i].x, s4.x, t4.x), bn_relu2(c[i].y, s4.y, t4.y), bn_relu2(c[i].z, s4.z, t4.z),
+                                   bn_relu2(c[i].w, s4.w, t4.w));
+            if (!okv[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp < N0) sA[c4 * S0 + hp] = v;
+        }
+    }
+    __syncthreads();
+    LWS_STAMPK(17, 1);
+
+    const int q_ = c4 >> 2, a_ = c4 & 3;
+    // ---- 2. depthwise A over R1: pixel p1 = (tid >> 3) + 32 i ----
+    {
+        float4 wd[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wd[tap] = *reinterpret_cast<const float4 *>(dwA + tap * 32 + c4 * 4);
+        const float4 *src = sA + c4 * S0;
+        float *dst = reinterpret_cast<float *>(sB + (4 * q_) * S1) + a_;
+#pragma unroll
+        for (int i = 0; i < Cfg::DITER; ++i) {
+            const int p1 = (tid >> 3) + 32 * i;
+            if (p1 < N1) {
+                const int ry = p1 / R1X, rx = p1 - ry * R1X;
+                const float4 *sp = src + ry * R0X + rx;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const float4 a = sp[(kh * DA) * R0X + kw * DA];
+                        const float4 w = wd[kh * 3 + kw];
+                        acc.x = fmaf(a.x, w.x, acc.x);
+                        acc.y = fmaf(a.y, w.y, acc.y);
+                        acc.z = fmaf(a.z, w.z, acc.z);
+                        acc.w = fmaf(a.w, w.w, acc.w);
+                    }
+                // channel 16q + 4a_ + e -> plane 4q + e, element a_
+                dst[(0 * S1 + p1) * 4] = acc.x;
+                dst[(1 * S1 + p1) * 4] = acc.y;
+                dst[(2 * S1 + p1) * 4] = acc.z;
+                dst[(3 * S1 + p1) * 4] = acc.w;
+            }
+        }
+    }
+    __syncthreads();
+    LWS_STAMPK(17, 2);
+
+    // ---- 3. pointwise A on MFMA over the flat 16-pixel tiles of R1; epilogue BN_B + ReLU -> sA (B's input image) ----
+    const int n = lane & 15, g = lane >> 4;
+    {
+        float4 aw[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) aw[q][mt] = pwA[(q * 2 + mt) * 64 + lane];
+        float4 es[2], et[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            es[mt] = *reinterpret_cast<const float4 *>(bnB_s + 16 * mt + 4 * g);
+            et[mt] = *reinterpret_cast<const float4 *>(bnB_t + 16 * mt + 4 * g);
+        }
+#pragma unroll
+        for (int k = 0; k < Cfg::TPW; ++k) {
+            const int tile = wave * Cfg::TPW + k;
+            if (tile < Cfg::NT1) {                                   // wave-uniform
+                const int p1 = tile * 16 + n;
+                float4 bv[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bv[q] = sB[(4 * q + g) * S1 + p1];
+                floatx4 acc[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(aw[q][mt], j), f4c(bv[q], j), acc[mt], 0, 0, 0);
+                const int ry = p1 / R1X, rx = p1 - ry * R1X;
+                const int gy = t.Y0 + (ry - DB) * M, gx = t.X0 + (rx - DB) * M;
+                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                if (p1 < N1) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        float4 v = make_float4(bn_relu2(acc[mt][0], es[mt].x, et[mt].x), bn_relu2(acc[mt][1], es[mt].y, et[mt].y),
+                                               bn_relu2(acc[mt][2], es[mt].z, et[mt].z), bn_relu2(acc[mt][3], es[mt].w, et[mt].w));
+                        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        sA[(4 * mt + g) * S0 + p1] = v;              // channels 16 mt + 4 g .. + 3 = group 4 mt + g
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    LWS_STAMPK(17, 3);
+
+    // ---- 4. depthwise B over the tile: pixel p = (tid >> 3) + 32 i -> row (tid >> 7) + 2 i, column (tid >> 3) & 15 ----
+    {
+        float4 wd[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wd[tap] = *reinterpret_cast<const float4 *>(dwB + tap * 32 + c4 * 4);
+        const float4 *src = sA + c4 * S0 + (tid >> 7) * R1X + ((tid >> 3) & 15);
+        float *dst = reinterpret_cast<float *>(sB + (4 * q_) * S1 + (tid >> 3)) + a_;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float4 a = src[(2 * i + kh * DB) * R1X + kw * DB];
+                    const float4 w = wd[kh * 3 + kw];
+                    acc.x = fmaf(a.x, w.x, acc.x);
+                    acc.y = fmaf(a.y, w.y, acc.y);
+                    acc.z = fmaf(a.z, w.z, acc.z);
+                    acc.w = fmaf(a.w, w.w, acc.w);
+                }
+            dst[(0 * S1 + 32 * i) * 4] = acc.x;
+            dst[(1 * S1 + 32 * i) * 4] = acc.y;
+            dst[(2 * S1 + 32 * i) * 4] = acc.z;
+            dst[(3 * S1 + 32 * i) * 4] = acc.w;
+        }
+    }
+    __syncthreads();
+    LWS_STAMPK(17, 4);
+
+    // ---- 5. pointwise B: wave handles tile rows 2*wave, 2*wave+1 x both output-channel tiles; store raw ----
+    float4 aw[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) aw[q][mt] = pwB[(q * 2 + mt) * 64 + lane];
+    floatx4 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    float4 bv[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) bv[r][q] = sB[(4 * q + g) * S1 + (2 * wave + r) * RT_X + n];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(aw[q][mt], j), f4c(bv[r][q], j), acc[r][mt], 0, 0, 0);
+    float *outb = out + (int64_t)t.b * H * W * 32;
+    const int gx = t.X0 + n * M;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int gy = t.Y0 + (2 * wave + r) * M;
+        if (gy < H && gx < W) {
+            float *o = outb + (gy * W + gx) * 32;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                store_act4(o + mt * 16 + 4 * g, make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]), wt);
+        }
+    }
+    LWS_STAMPK(17, 5);
+}
+
+// =============================================================================================
 // refinement2[0] (submodules.py:304-309): BatchNorm(64) -> ReLU -> Conv 3x3 dilation 8, 64 -> 32, on the
 // concatenation [refined_left, refined_disp] (models.py:160) -- the concat is never materialised: the two
 // channels-last maps are staged side by side.  fp32-MFMA implicit GEMM, K = 9 taps x 64 channels = 144 MFMAs per
@@ -1039,6 +1271,45 @@ int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, i
                        use_wt_stores((size_t)B * H * W * 128), (const float *)nullptr, 0, 0, (float *)nullptr);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
+}
+
+// blocks a then b in one launch (k_ref_dws2); the dilation pairs of the refinement: (2,4) (4,8) (8,16) (8,4) (2,1)
+bool ref_dws_pair_can_fuse(const RefDws &a, const RefDws &b)
+{
+    const int M = a.dil < b.dil ? a.dil : b.dil;
+    if (M < 1 || a.dil % M || b.dil % M) return false;
+    const int da = a.dil / M, db = b.dil / M;
+    return (da == 1 && db == 2) || (da == 2 && db == 1);
+}
+
+template <int DA, int DB>
+static int dws2_launch(const RefDws &a, const RefDws &b, const float *in, float *out, int B, int H, int W, int M, hipStream_t st)
+{
+    using Cfg = Dws2Cfg<DA, DB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ref_dws2<DA, DB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    const int nbx = cdiv(W, RT_X * M), nby = cdiv(H, RT_Y * M);
+    dim3 grid(nbx * nby * M * M * B), block(256);
+    hipLaunchKernelGGL((k_ref_dws2<DA, DB>), grid, block, Cfg::LDS_BYTES, st, in, a.bn_s, a.bn_t, a.dw,
+                       reinterpret_cast<const float4 *>(a.pw), b.bn_s, b.bn_t, b.dw, reinterpret_cast<const float4 *>(b.pw), out,
+                       H, W, M, nbx, nby, use_wt_stores((size_t)B * H * W * 128));
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+int launch_ref_dws_pair(const RefDws &a, const RefDws &b, const float *in, float *out, int B, int H, int W, hipStream_t st)
+{
+    if (!ref_dws_pair_can_fuse(a, b)) {
+        set_error("ref_dws_pair: dilations %d, %d cannot be fused", a.dil, b.dil);
+        return LWS_ERR_INVALID;
+    }
+    const int M = a.dil < b.dil ? a.dil : b.dil;
+    if (a.dil == M) return dws2_launch<1, 2>(a, b, in, out, B, H, W, M, st);
+    return dws2_launch<2, 1>(a, b, in, out, B, H, W, M, st);
 }
 
 // 1 -> 32 first convolution + the first depthwise-separable block in one launch (disparity branch of refinement1)

@@ -183,14 +183,21 @@ def test_feature_extraction_golden(dev, model):
         np.testing.assert_allclose(got[i].cpu().numpy(), g[f"featL{i}"], rtol=0, atol=3e-5)
 
 
-@pytest.mark.parametrize("B,H,W", [(1, 64, 256), (2, 40, 72), (1, 136, 152)])
-def test_refine_bitexact(dev, model, B, H, W):
+@pytest.mark.parametrize("B,H,W", [(1, 64, 256), (2, 40, 72), (1, 136, 152), (1, 63, 255)])
+@pytest.mark.parametrize("fuse_dws", [0, 1])
+def test_refine_bitexact(dev, model, B, H, W, fuse_dws):
+    """fuse_dws = 1: the depthwise-separable blocks run pairwise in k_ref_dws2 (dilation pairs (2,4), (8,16), (4,8), (8,4),
+    (2,1)): the same fmaf / MFMA chains, so the same bits."""
     from lwsnet_amd import ops
     from oracle import c_oracle as C
     rng = np.random.default_rng(9)
     left = rng.standard_normal((B, 3, H, W)).astype(np.float32)
     pred3 = (rng.random((B, 1, H, W)) * 150.0).astype(np.float32)
-    got = ops.refine(model._h, cu(left, dev), cu(pred3, dev))
+    model.set_option("fuse_dws", fuse_dws)
+    try:
+        got = ops.refine(model._h, cu(left, dev), cu(pred3, dev))
+    finally:
+        model.set_option("fuse_dws", 0)
     assert_bits(got, C.refine(left, pred3, model.state_dict()), "refine")
 
 
@@ -261,8 +268,8 @@ def test_forward_repeatable_batch8(dev, model):
 
 
 OPTION_PLANS = [{"left_at": 0}, {"left_at": 2}, {"split_heads": 1}, {"split_heads": 0}, {"fuse_shift": 0},
-                {"fuse_first": 0}, {"defer_upsample": 0}, {"left_at": 2, "split_heads": 1},
-                {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0}]
+                {"fuse_first": 0}, {"defer_upsample": 0}, {"fuse_dws": 1}, {"left_at": 2, "split_heads": 1},
+                {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0, "fuse_dws": 1}]
 
 
 @pytest.mark.parametrize("plan", OPTION_PLANS, ids=lambda p: ",".join(f"{k}={v}" for k, v in p.items()))

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Per-kernel timing of the refinement (lws_refine) on the GPU, fused depthwise pairs on and off (development aid).
+
+    python tools/rbench.py [--batch B] [--size HxW] [--iters N]"""
+import argparse
+import ctypes
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch   # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--size", default="256x512")
+    ap.add_argument("--iters", type=int, default=50)
+    a = ap.parse_args()
+    H, W = [int(v) for v in a.size.split("x")]
+    from lwsnet_amd import _lib, ops
+    from lwsnet_amd.models import LWSNet
+    from lwsnet_amd.weights import default_args, make_state_dict
+    dev = torch.device("cuda:0")
+    m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
+    lib = _lib.load()
+    left = torch.randn((a.batch, 3, H, W), device=dev)
+    p3 = torch.rand((a.batch, 1, H, W), device=dev) * 100
+    outs = {}
+    for fuse in (0, 1):
+        m.set_option("fuse_dws", fuse)
+        for _ in range(5):
+            outs[fuse] = ops.refine(m._h, left, p3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            ops.refine(m._h, left, p3)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / a.iters
+        _lib.check(lib.lws_profile_enable(m._h, -1))
+        for _ in range(a.iters):
+            ops.refine(m._h, left, p3)
+        torch.cuda.synchronize()
+        tot = (ctypes.c_double * _lib.LWS_KC_COUNT)()
+        cnt = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
+        _lib.check(lib.lws_profile_read(m._h, tot, cnt))
+        _lib.check(lib.lws_profile_enable(m._h, 0))
+        print(f"fuse_dws={fuse} B={a.batch} {H}x{W}: wall {wall * 1e6:.1f} us per lws_refine; kernels (with event overhead):")
+        for kc in range(_lib.LWS_KC_COUNT):
+            if cnt[kc]:
+                print(f"   {lib.lws_kernel_class_name(kc).decode():12s} x{cnt[kc] // a.iters:2d} avg {tot[kc] / cnt[kc] * 1e3:7.2f} us")
+    print("bitwise equal:", bool(torch.equal(outs[0], outs[1])))
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,7 @@ KERNELS = {  # name: (stamp id, translation unit, driver, arg)
     "feat": (7, "conv2d", "feat", None), "pair0": (13, "conv2d", "feat", None), "pair1": (14, "conv2d", "feat", None),
     "pair2": (15, "conv2d", "feat", None), "pair3": (16, "conv2d", "feat", None), "ref_last": (9, "conv2d", "refine", None),
     "warp2": (10, "volume", "stages", None), "warp3": (10, "volume", "stages", None),
+    "dws2": (17, "conv2d", "refine", None),
 }
 what = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -52,9 +53,11 @@ torch.cuda.synchronize()
 n = 4096 * 8
 buf = (ctypes.c_ulonglong * n)()
 assert getattr(lib, "lws_debug_read_stamps_" + TU)(buf, n) == 0
-s = np.array(buf, dtype=np.int64).reshape(-1, 8)[:, :4]
+s = np.array(buf, dtype=np.int64).reshape(-1, 8)
 s = s[(s[:, 0] > 0) & (s[:, 3] > 0)]
+last = 5 if (s[:, 5] > 0).all() else 3
 print(f"{what} B={B}: workgroups with stamps: {len(s)} (last launch of this kernel)")
-for a, b in ((0, 1), (1, 2), (2, 3), (0, 3)):
+print(f"  whole launch (first start -> last end): {s[:, last].max() - s[:, 0].min()} cycles; start spread {s[:, 0].max() - s[:, 0].min()}")
+for a, b in [(i, i + 1) for i in range(last)] + [(0, last)]:
     d = s[:, b] - s[:, a]
     print(f"  stamp {a}->{b}: median {np.median(d):8.0f}  p10 {np.percentile(d,10):8.0f}  p90 {np.percentile(d,90):8.0f} cycles")
