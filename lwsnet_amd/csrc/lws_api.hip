@@ -752,7 +752,8 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"fuse_shift", &h->opt.fuse_shift},
                                                      {"fuse_first", &h->opt.fuse_first},
                                                      {"defer_upsample", &h->opt.defer_upsample},
-                                                     {"fuse_dws", &h->opt.fuse_dws}};
+                                                     {"fuse_dws", &h->opt.fuse_dws},
+                                                     {"mid8_stream", &h->opt.mid8_stream}};
     for (auto &e : tab)
         if (strcmp(e.name, name) == 0) return e.slot;
     return nullptr;
@@ -770,6 +771,7 @@ int lws_set_option(lws_handle h, const char *name, int value)
     else
         LWS_CHECK_ARG(value == 0 || value == 1, "lws_set_option: %s must be 0 or 1 (got %d)", name, value);
     *slot = value;
+    for (int i = 0; i < 3; ++i) h->stage[i].mid8_stream = h->opt.mid8_stream;
     return LWS_OK;
 }
 

@@ -56,7 +56,7 @@ static inline int use_wt_stores(size_t out_bytes) { return out_bytes <= ((size_t
 // Diagnostic builds only (LWS_EXTRA_FLAGS="-DLWS_STAMPS=<kernel id>"; tools/stamps.py): every workgroup of the selected
 // kernel stores s_memtime stamps of its phases in a per-translation-unit buffer.  The shipped library compiles
 // LWS_STAMPK to nothing.  Kernel ids: 1 mid16, 2 mid8, 3 conv3d_last, 4 conv3d_first, 5 ref_dws, 6 ref_conv64,
-// 7 conv2d_nchw, 8 ref_first, 9 ref_last, 10 volume_warp, 11 volume_shift, 12 softargmin_upsample, 13..16 conv2d_pair (dres0, dres1, conv1+2, conv3+4), 17 ref_dws2.
+// 7 conv2d_nchw, 8 ref_first, 9 ref_last, 10 volume_warp, 11 volume_shift, 12 softargmin_upsample, 13..16 conv2d_pair (dres0, dres1, conv1+2, conv3+4), 17 ref_dws2, 18 conv3d_mid8s.
 #ifdef LWS_STAMPS
 #define LWS_DEFINE_STAMPS(tu)                                                                                      \
     __device__ unsigned long long g_stamps_##tu[4096 * 8];                                                         \
@@ -93,6 +93,7 @@ struct Conv3dLayer {
 
 struct Stage3d {
     int c3 = 0;
+    int mid8_stream = 0;               // k_conv3d_mid8s (d-streaming) for the 8 -> 8 layers: 0 = never (default), 1 = always
     std::vector<Conv3dLayer> layers;   // layers_3d + 2
 };
 
@@ -145,6 +146,7 @@ struct lws_ctx {
         int fuse_shift = 1;        // stage-1 volume inside the first Conv3D launch
         int fuse_first = 1;        // refinement1_disp's 1 -> 32 convolution inside its first depthwise block
         int defer_upsample = 1;    // batches <= 2: consumers evaluate the stage-2/3 maps (no k_upsample_add launches)
+        int mid8_stream = 0;       // 8 -> 8 Conv3D layers in the d-streaming form (k_conv3d_mid8s; measured r02: no faster)
         int fuse_dws = 0;          // consecutive depthwise-separable blocks of the refinement pairwise in one launch (measured slower, r02)
     } opt;
     unsigned prof_mask = 0;                  // kernel classes being timed in the current call

@@ -450,6 +450,171 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
 }
 
 // =============================================================================================
+// Middle layers, C3 == 8, d-streaming form (k_conv3d_mid8s): the same MFMA scheme and the same chains as k_conv3d_mid8
+// (rows = (x parity, cout), 72 resident A fragments, planar LDS image), but a workgroup owns a TY x 32 column of the
+// volume over ALL d and walks it two planes at a time.  The LDS image is a ring of 6 d-planes: planes d-1 .. d+2 feed
+// the two planes being computed (two accumulator chains per wave that share every A fragment), while planes d+3, d+4
+// are in flight from L2 into registers under the MFMAs and are written to the two free slots afterwards -- one barrier
+// per pair of planes.  Against the 3-deep tile this removes the d halo (5/3 of the reads) and the "everyone stages,
+// then everyone computes" phase structure (profiles/r01: SQ_WAIT_INST_ANY 65 % at stage 3): only the first four planes
+// are loaded with nothing to hide behind.  39.4 KB of LDS: 4 workgroups per CU.
+// =============================================================================================
+template <int TY>
+struct Mid8sCfg {
+    static constexpr int HY = TY + 2, HX = 34;
+    static constexpr int NV = HY * HX;                              // voxels of one d-plane of the halo column
+    static constexpr int PS = (NV % 2 == 0) ? NV + 1 : NV;          // odd channel-plane stride (floats)
+    static constexpr int SLOT = 8 * PS;                             // one d-plane: 8 channel planes
+    static constexpr int NSLOT = 6;
+    static constexpr int ITEMS = NV * 2;                            // (voxel, half) items of one d-plane
+    static constexpr int SITER = (ITEMS + 64 * TY - 1) / (64 * TY);
+    static constexpr int LDS_BYTES = NSLOT * SLOT * 4;
+};
+
+template <int TY>
+__global__ __launch_bounds__(64 * TY) void k_conv3d_mid8s(const float *__restrict__ in,      // [B,D,h,w,8]
+                                                         const float *__restrict__ wpk,     // [18][64][4] A fragments
+                                                         const float *__restrict__ bn_s,    // next layer BN [8]
+                                                         const float *__restrict__ bn_t,
+                                                         float *__restrict__ out, int D, int h, int w,
+                                                         int tiles_x, int wt)
+{
+    using Cfg = Mid8sCfg<TY>;
+    constexpr int HY = Cfg::HY, HX = Cfg::HX, PS = Cfg::PS, SLOT = Cfg::SLOT, NSLOT = Cfg::NSLOT, SITER = Cfg::SITER;
+    constexpr int NT = 64 * TY;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int b = blockIdx.y;
+    const int x0 = tx * 32, y0 = ty * TY;
+    const float *inb = in + (int64_t)b * D * h * w * 8;
+    LWS_STAMPK(18, 0);
+
+    const int xpar = g >> 1, cb = 4 * (g & 1);
+    const float4 es8 = *reinterpret_cast<const float4 *>(bn_s + cb);
+    const float4 et8 = *reinterpret_cast<const float4 *>(bn_t + cb);
+    float wa[72];
+#pragma unroll
+    for (int s4 = 0; s4 < 18; ++s4) {
+        const float4 v = reinterpret_cast<const float4 *>(wpk)[s4 * 64 + lane];
+        wa[4 * s4 + 0] = v.x;
+        wa[4 * s4 + 1] = v.y;
+        wa[4 * s4 + 2] = v.z;
+        wa[4 * s4 + 3] = v.w;
+    }
+
+    // staging of one d-plane: item = (voxel v of the (TY+2) x 34 halo plane, channel half); per-thread item geometry is
+    // the same for every plane, so it is computed once
+    int soff[SITER], sdst[SITER];
+    bool sok[SITER];
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int it = tid + i * NT;
+        const int half = it & 1, v = it >> 1;
+        const int hx = v % HX, hy = v / HX;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        sok[i] = it < Cfg::ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        soff[i] = sok[i] ? (gy * w + gx) * 8 + half * 4 : 0;          // offset inside one d-plane (h*w*8 floats < 2^31)
+        sdst[i] = it < Cfg::ITEMS ? (half * 4) * PS + v : -1;
+    }
+    const int64_t dplane = (int64_t)h * w * 8;
+    auto load_plane = [&](int d, float4 (&c)[SITER]) {                   // d may be outside [0, D): zeros then
+        const bool dok = d >= 0 && d < D;
+        const float *src = inb + (dok ? (int64_t)d * dplane : 0);
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) c[i] = *reinterpret_cast<const float4 *>(src + soff[i]);
+        if (!dok) {
+#pragma unroll
+            for (int i = 0; i < SITER; ++i) c[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto write_plane = [&](int d, const float4 (&c)[SITER]) {
+        float *base = lds + ((d + NSLOT) % NSLOT) * SLOT;                 // plane d lives in slot (d mod 6), d >= -1
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            if (sdst[i] >= 0) {
+                const float4 v4 = sok[i] ? c[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float *dst = base + sdst[i];
+                dst[0] = v4.x;
+                dst[PS] = v4.y;
+                dst[2 * PS] = v4.z;
+                dst[3 * PS] = v4.w;
+            }
+        }
+    };
+
+    // ---- prologue: planes -1 (zeros), 0, 1, 2 ----
+    float4 ca[SITER], cc[SITER];
+    {
+        float4 c0[SITER], c1[SITER];
+        load_plane(0, c0);
+        load_plane(1, c1);
+        load_plane(2, ca);
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) cc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        write_plane(-1, cc);
+        write_plane(0, c0);
+        write_plane(1, c1);
+        write_plane(2, ca);
+    }
+    __syncthreads();
+    LWS_STAMPK(18, 1);
+
+    const int rbase = g * PS + wave * HX + 2 * n;            // this wave's output row `wave` of the column; halo row = wave + kh
+    float *outb = out + (int64_t)b * D * h * w * 8;
+    const int gx = x0 + 2 * n + xpar, gy = y0 + wave;
+
+#pragma unroll 1
+    for (int d = 0; d < D; d += 2) {
+        // next two planes: global -> registers, in flight under the MFMAs below
+        load_plane(d + 3, ca);
+        load_plane(d + 4, cc);
+        const bool two = d + 1 < D;                         // wave-uniform: the last pass of an odd D computes one plane
+        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const float *p0 = lds + ((d - 1 + kd + NSLOT) % NSLOT) * SLOT + rbase;     // plane d - 1 + kd   (output plane d)
+            const float *p1 = lds + ((d + kd + NSLOT) % NSLOT) * SLOT + rbase;         // plane d + kd       (output plane d + 1)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int step = ((kd * 3 + kh) * 4 + t) * 2 + half;
+                        const int off = half * 4 * PS + kh * HX + t;
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], p0[off], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], p1[off], acc1, 0, 0, 0);
+                    }
+        }
+        // epilogue of the two planes: next layer's BatchNorm + ReLU, 16-byte stores
+        if (gy < h && gx < w) {
+            float4 v;
+            v.x = bn_relu(acc0[0], es8.x, et8.x);
+            v.y = bn_relu(acc0[1], es8.y, et8.y);
+            v.z = bn_relu(acc0[2], es8.z, et8.z);
+            v.w = bn_relu(acc0[3], es8.w, et8.w);
+            store_act4(outb + (((int64_t)d * h + gy) * w + gx) * 8 + cb, v, wt);
+            if (two) {
+                v.x = bn_relu(acc1[0], es8.x, et8.x);
+                v.y = bn_relu(acc1[1], es8.y, et8.y);
+                v.z = bn_relu(acc1[2], es8.z, et8.z);
+                v.w = bn_relu(acc1[3], es8.w, et8.w);
+                store_act4(outb + (((int64_t)(d + 1) * h + gy) * w + gx) * 8 + cb, v, wt);
+            }
+        }
+        // planes d + 3, d + 4 take the slots of d - 3, d - 2, last read in the previous pass (its closing barrier is behind
+        // every wave); the next pass reads d + 1 .. d + 4
+        write_plane(d + 3, ca);
+        write_plane(d + 4, cc);
+        __syncthreads();
+    }
+    LWS_STAMPK(18, 2);
+}
+
+// =============================================================================================
 // First layer, C3 == 8 (stages 2 and 3), on fp32 MFMA: k_conv3d_mid8's scheme with one input channel.  Rows =
 // (x parity, cout), columns = voxel pairs, K = the four x positions t = 0..3 both parities read, so each (kd,kh) is ONE
 // MFMA whose A operand is W[cout][kd][kh][t - xpar] (zero outside 0..2) and whose B operand is one ds_read_b32 of the
@@ -961,6 +1126,18 @@ static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out,
     return LWS_OK;
 }
 
+template <int TY>
+static int mid8s_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w, hipStream_t st)
+{
+    using Cfg = Mid8sCfg<TY>;
+    const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY);
+    dim3 grid(tiles_x * tiles_y, B), block(64 * TY);
+    hipLaunchKernelGGL((k_conv3d_mid8s<TY>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w, s.layers[layer + 1].bn_s,
+                       s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, /*wt=*/0);
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
 // layer = 1 .. layers_3d (the C3 -> C3 convolutions)
 int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *act_out, int B, int D, int h,
                       int w, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
@@ -969,6 +1146,11 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
         case 8: {
             // (whole-D tiles, 9 rows per wave, measured r01: 19.3 vs 17.0 us at B=1 256x512 -- one wave per SIMD cannot
             // overlap its own staging with its MFMAs, three co-resident small workgroups can)
+            // d-streaming form (option "mid8_stream").  Measured r02 (tools/sbench.py, us per launch, 3-deep tiles vs d-streaming):
+            // stage 3 (9 x 128 x 256) 19.1 vs 22.0 at B = 1, 31.4 vs 30.9 at B = 2, 105.7 vs 107.1 at B = 8; stage 2
+            // (9 x 64 x 128) 8.8 vs 20.2 at B = 1 (64 workgroups), 32.7 vs 32.2 at B = 8; 8 x 368x1232: 371.5 vs 377.4.  Both forms
+            // level off at ~77 TF useful = 103 TF issued (0.65 of the fp32-MFMA peak): the staging phases were not the limit.
+            if (s.mid8_stream > 0 && D >= 3) return mid8s_launch<4>(s, layer, act_in, act_out, B, D, h, w, st);
             return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
         }
         case 16: return mid16_launch<16, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);

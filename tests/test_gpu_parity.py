@@ -102,8 +102,14 @@ def test_conv3d_stack_bitexact(dev, model, stage, shape):
     from lwsnet_amd import ops
     from oracle import c_oracle as C
     c = (np.random.default_rng(stage + 1).random(shape) * 12.0).astype(np.float32)
-    got = ops.conv3d_stack(model._h, stage, cu(c, dev))
-    assert_bits(got, C.conv3d_stack(c, model.state_dict(), stage), f"conv3d_stack stage {stage} {shape}")
+    want = C.conv3d_stack(c, model.state_dict(), stage)
+    for stream in ((0, 1) if stage > 0 else (0,)):           # 8 -> 8 layers: 3-deep tiles and the d-streaming form
+        model.set_option("mid8_stream", stream)
+        try:
+            got = ops.conv3d_stack(model._h, stage, cu(c, dev))
+        finally:
+            model.set_option("mid8_stream", 0)
+        assert_bits(got, want, f"conv3d_stack stage {stage} {shape} mid8_stream={stream}")
 
 
 @pytest.mark.parametrize("stage", [0, 1])
@@ -268,7 +274,8 @@ def test_forward_repeatable_batch8(dev, model):
 
 
 OPTION_PLANS = [{"left_at": 0}, {"left_at": 2}, {"split_heads": 1}, {"split_heads": 0}, {"fuse_shift": 0},
-                {"fuse_first": 0}, {"defer_upsample": 0}, {"fuse_dws": 1}, {"left_at": 2, "split_heads": 1},
+                {"fuse_first": 0}, {"defer_upsample": 0}, {"fuse_dws": 1}, {"mid8_stream": 1},
+                {"left_at": 2, "split_heads": 1},
                 {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0, "fuse_dws": 1}]
 
 

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--size", default="256x512")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="name=value launch-plan option (lws_set_option)")
     a = ap.parse_args()
     H, W = [int(v) for v in a.size.split("x")]
     from lwsnet_amd import _lib, ops
@@ -33,6 +34,9 @@ def main():
     sd = make_state_dict(7)
     m = LWSNet(margs, device=dev).set_state_dict(sd).eval()
     lib = _lib.load()
+    for o in a.opt:
+        k, v = o.split("=")
+        m.set_option(k, int(v))
     B = a.batch
     rng = np.random.default_rng(0)
     shapes = [(B, 16, H // 8, W // 8), (B, 16, H // 4, W // 4), (B, 8, H // 2, W // 2)]

@@ -14,7 +14,7 @@ KERNELS = {  # name: (stamp id, translation unit, driver, arg)
     "feat": (7, "conv2d", "feat", None), "pair0": (13, "conv2d", "feat", None), "pair1": (14, "conv2d", "feat", None),
     "pair2": (15, "conv2d", "feat", None), "pair3": (16, "conv2d", "feat", None), "ref_last": (9, "conv2d", "refine", None),
     "warp2": (10, "volume", "stages", None), "warp3": (10, "volume", "stages", None),
-    "dws2": (17, "conv2d", "refine", None),
+    "dws2": (17, "conv2d", "refine", None), "mid8s3": (18, "conv3d", "stack", 2), "mid8s2": (18, "conv3d", "stack", 1),
 }
 what = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
