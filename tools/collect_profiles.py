@@ -11,8 +11,11 @@ for f in os.listdir(dst):
 shutil.copy(f"{src}/kt/run_kernel_stats.csv", f"{dst}/kernel_stats_b1_256x512.csv")
 shutil.copy(f"{src}/kt_bench.json", f"{dst}/bench_under_rocprof.json")
 for n in os.listdir(src):
-    if n.startswith("bench_") and n.endswith(".json"):
+    if (n.startswith("bench_") and n.endswith(".json")) or n.startswith(("sbench_", "rbench_")):
         shutil.copy(f"{src}/{n}", f"{dst}/{n}")
+for d, name in (("kt8", "kernel_stats_b8_256x512.csv"), ("ktc3", "kernel_stats_b8_368x1232.csv")):
+    if os.path.isfile(f"{src}/{d}/run_kernel_stats.csv"):
+        shutil.copy(f"{src}/{d}/run_kernel_stats.csv", f"{dst}/{name}")
 out = {}
 for name in ("fetch", "write"):
     rows = list(csv.DictReader(open(f"{src}/{name}/run_counter_collection.csv")))

@@ -21,3 +21,13 @@ cd "$R"
 # keep the merge-back small: the kernel trace itself is large and not needed
 rm -f "$O"/kt/run_kernel_trace.csv
 tail -c 400 "$O/bench_b1.json"; echo; tail -3 "$O/smoke.log"
+# batch-8 kernel statistics (BASELINE configs 4 / 3 per-GPU workloads)
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt8" -o run -- python3 "$R/bench.py" --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --no-pipelined > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ktc3" -o run -- python3 "$R/bench.py" --batch 8 --size 368x1232 --steps 8 --warmup 3 --no-cpu-baseline --no-pipelined > /dev/null 2>&1
+rm -f "$O"/kt8/run_kernel_trace.csv "$O"/ktc3/run_kernel_trace.csv
+cd "$R"
+python tools/sbench.py > "$O/sbench_b1.txt" 2> /dev/null
+python tools/sbench.py --batch 8 > "$O/sbench_b8.txt" 2> /dev/null
+python tools/rbench.py > "$O/rbench_b1.txt" 2> /dev/null
+python tools/rbench.py --batch 8 --iters 20 > "$O/rbench_b8.txt" 2> /dev/null
