@@ -841,17 +841,60 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
 // Every value is produced by the same fmaf / MFMA chains as two k_ref_dws launches: bit-identical.
 // LDS 70.7 KB (2 workgroups per CU); reads 2.4 lines per output pixel instead of 2 x 1.56 + the intermediate's write + read.
 // =============================================================================================
+// Depthwise 3x3 (dilation D) for a VERTICAL strip of S pixels spaced D rows apart, one 4-channel group: the 3 x (S + 2)
+// taps the strip touches are read once (instead of 9 per pixel) and every pixel still accumulates its own taps in (kh, kw)
+// ascending order -- the same fmaf chain as one pixel at a time.  src points at the strip's first pixel's (kh, kw) = (0, 0)
+// tap; wv (this channel group's [tap][4] weights) is wave-uniform -- the lanes of a wave sweep pixels of ONE channel group --
+// so it sits in SGPRs.
+template <int D, int S>
+__device__ __forceinline__ void dw_vstrip(const float4 *src, int row_stride, const float (&wv)[9][4], float4 (&acc)[S])
+{
+    // all 3 (S + 2) taps are requested before the first fmaf: one LDS round trip per strip instead of one per tap (left to
+    // itself hipcc keeps two ds_read_b128 in flight and waits on each); the 36 scalar weights were loaded by the caller
+    float4 tap[S + 2][3];
+#pragma unroll
+    for (int c = 0; c < S + 2; ++c)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) tap[c][kw] = src[(c * D) * row_stride + kw * D];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s_ = 0; s_ < S; ++s_) acc[s_] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < S + 2; ++c)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const float4 a = tap[c][kw];
+#pragma unroll
+            for (int s_ = 0; s_ < S; ++s_) {
+                const int kh = c - s_;
+                if (kh >= 0 && kh <= 2) {
+                    acc[s_].x = fmaf(a.x, wv[kh * 3 + kw][0], acc[s_].x);
+                    acc[s_].y = fmaf(a.y, wv[kh * 3 + kw][1], acc[s_].y);
+                    acc[s_].z = fmaf(a.z, wv[kh * 3 + kw][2], acc[s_].z);
+                    acc[s_].w = fmaf(a.w, wv[kh * 3 + kw][3], acc[s_].w);
+                }
+            }
+        }
+}
+
 template <int DA, int DB>
 struct Dws2Cfg {
     static constexpr int R1Y = RT_Y + 2 * DB, R1X = RT_X + 2 * DB, N1 = R1Y * R1X;   // block A's output region
     static constexpr int R0Y = R1Y + 2 * DA, R0X = R1X + 2 * DA, N0 = R0Y * R0X;     // block A's input region
     static constexpr int NT1 = (N1 + 15) / 16, TPW = (NT1 + 3) / 4;                 // pointwise-A pixel tiles (per wave)
-    // plane strides in float4 with (4 * stride) % 64 an odd multiple of 8 dwords: the 8 planes of a pixel hit 64 banks
+    // R0 / R1 images: planar by 4-channel group, plane stride in float4 with (4 * stride) % 64 an odd multiple of 8 dwords
     static constexpr int pad(int n) { return n + ((2 - n % 4) + 4) % 4; }
-    static constexpr int S0 = pad(N0), S1 = pad(NT1 * 16);
-    static constexpr int SITER = (N0 * 8 + 255) / 256, DITER = (N1 + 31) / 32;
-    static constexpr int LDS_BYTES = 8 * (S0 + S1) * 16;
-    static_assert(S0 >= N1 && S1 >= RT_Y * RT_X, "aliased images must fit");
+    static constexpr int S0 = pad(N0);
+    // depthwise results: planar by CHANNEL, [32][SP] floats, SP % 32 == 16: the MFMA B operand of lane (n, g) is one
+    // ds_read_b32 per (q, j) at plane 16 q + 4 j + g, pixel 16 tile + n -- lanes (n, g in {0,1}) hit 32 different banks
+    static constexpr int SP = ((NT1 * 16 + 15) / 32) * 32 + 16;
+    static constexpr int SITER = (N0 * 8 + 255) / 256;
+    // vertical depthwise strips: SVA rows spaced DA in R1 (lanes = strips x R1X columns), SVB = 2 rows spaced DB in the tile
+    static constexpr int SVA = DA == 1 ? 4 : 5, NVA = R1Y / SVA, LANES_A = NVA * R1X;
+    static constexpr int SVB = 2, NVB = RT_Y / SVB;
+    static_assert(R1Y % (SVA * DA) == 0 && RT_Y % (SVB * DB) == 0 && LANES_A <= 64 && NVB * RT_X == 64, "strip geometry");
+    static constexpr int LDS_BYTES = 8 * S0 * 16 + 32 * SP * 4;
+    static_assert(S0 >= N1 && SP >= NT1 * 16 && SP >= RT_Y * RT_X, "aliased images must fit");
 };
 
 template <int DA, int DB>
@@ -863,14 +906,28 @@ __global__ __launch_bounds__(256) void k_ref_dws2(const float *__restrict__ in, 
                                                   float *__restrict__ out, int H, int W, int M, int nbx, int nby, int wt)
 {
     using Cfg = Dws2Cfg<DA, DB>;
-    constexpr int R1X = Cfg::R1X, N1 = Cfg::N1, R0X = Cfg::R0X, N0 = Cfg::N0, S0 = Cfg::S0, S1 = Cfg::S1;
+    constexpr int R1X = Cfg::R1X, N1 = Cfg::N1, R0X = Cfg::R0X, N0 = Cfg::N0, S0 = Cfg::S0, SP = Cfg::SP;
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-    float4 *sA = lds4;                 // [8][S0]: R0 image (BN_A+ReLU'd input), later the R1 image (B's input)
-    float4 *sB = lds4 + 8 * S0;        // [8][S1]: depthwise results in B-operand order (A over R1, later B over the tile)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float4 *sA = lds4;                                          // [8][S0]: R0 image (BN_A+ReLU'd input), later the R1 image
+    float *sP = reinterpret_cast<float *>(lds4 + 8 * S0);       // [32][SP]: depthwise results (A over R1, later B over the tile)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR: the depthwise weight addresses become scalar loads
     const RefTile t = ref_tile(M, nbx, nby);
     const int c4 = tid & 7;
+    const int n = lane & 15, g = lane >> 4;
     LWS_STAMPK(17, 0);
+
+    // depthwise weights of this wave's two channel groups (wave-uniform addresses -> s_load into SGPRs), requested first so
+    // that the scalar-cache round trip hides behind the staging loads
+    float wdw[2][9][4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wdw[pass][t9][e] = dwA[t9 * 32 + 4 * (2 * wave + pass) + e];
+    // per-lane parameters of the two pointwise steps, loaded behind the staging loads
+    float4 awA[2][2], awB[2][2], es[2], et[2];
 
     // ---- 1. stage R0: item = (pixel hp, 4-channel group c4); all loads in flight before the first LDS write ----
     {
@@ -889,6 +946,18 @@ __global__ __launch_bounds__(256) void k_ref_dws2(const float *__restrict__ in, 
             c[i] = *reinterpret_cast<const float4 *>(inb + off);
         }
 #pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                awA[q][mt] = pwA[(q * 2 + mt) * 64 + lane];
+                awB[q][mt] = pwB[(q * 2 + mt) * 64 + lane];
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            es[mt] = *reinterpret_cast<const float4 *>(bnB_s + 16 * mt + 4 * g);
+            et[mt] = *reinterpret_cast<const float4 *>(bnB_t + 16 * mt + 4 * g);
+        }
+#pragma unroll
         for (int i = 0; i < Cfg::SITER; ++i) {
             const int hp = (tid >> 3) + 32 * i;
             float4 v = make_float4(bn_relu2(c[i].x, s4.x, t4.x), bn_relu2(c[i].y, s4.y, t4.y), bn_relu2(c[i].z, s4.z, t4.z),
@@ -900,85 +969,86 @@ __global__ __launch_bounds__(256) void k_ref_dws2(const float *__restrict__ in, 
     __syncthreads();
     LWS_STAMPK(17, 1);
 
-    const int q_ = c4 >> 2, a_ = c4 & 3;
-    // ---- 2. depthwise A over R1: pixel p1 = (tid >> 3) + 32 i ----
+    // ---- 2. depthwise A over R1.  Wave w owns channel groups 2 w and 2 w + 1 (weights in SGPRs); its lanes are
+    //         (strip, column): a vertical strip of SVA rows spaced DA, so consecutive lanes read and write consecutive
+    //         LDS addresses (conflict-free) and the strip's taps are read once ----
     {
-        float4 wd[9];
+        const int st_ = lane / R1X, x = lane - st_ * R1X;
+        const int ry0 = (st_ % DA) + DA * Cfg::SVA * (st_ / DA);            // first row of the strip
+        if (lane < Cfg::LANES_A) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) wd[tap] = *reinterpret_cast<const float4 *>(dwA + tap * 32 + c4 * 4);
-        const float4 *src = sA + c4 * S0;
-        float *dst = reinterpret_cast<float *>(sB + (4 * q_) * S1) + a_;
+            for (int pass = 0; pass < 2; ++pass) {
+                const int cg = 2 * wave + pass;                             // wave-uniform channel group
+                float4 acc[Cfg::SVA];
+                dw_vstrip<DA, Cfg::SVA>(sA + cg * S0 + ry0 * R0X + x, R0X, wdw[pass], acc);
 #pragma unroll
-        for (int i = 0; i < Cfg::DITER; ++i) {
-            const int p1 = (tid >> 3) + 32 * i;
-            if (p1 < N1) {
-                const int ry = p1 / R1X, rx = p1 - ry * R1X;
-                const float4 *sp = src + ry * R0X + rx;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const float4 a = sp[(kh * DA) * R0X + kw * DA];
-                        const float4 w = wd[kh * 3 + kw];
-                        acc.x = fmaf(a.x, w.x, acc.x);
-                        acc.y = fmaf(a.y, w.y, acc.y);
-                        acc.z = fmaf(a.z, w.z, acc.z);
-                        acc.w = fmaf(a.w, w.w, acc.w);
-                    }
-                // channel 16q + 4a_ + e -> plane 4q + e, element a_
-                dst[(0 * S1 + p1) * 4] = acc.x;
-                dst[(1 * S1 + p1) * 4] = acc.y;
-                dst[(2 * S1 + p1) * 4] = acc.z;
-                dst[(3 * S1 + p1) * 4] = acc.w;
+                for (int s_ = 0; s_ < Cfg::SVA; ++s_) {
+                    float *dst = sP + (4 * cg) * SP + (ry0 + DA * s_) * R1X + x;
+                    dst[0] = acc[s_].x;
+                    dst[SP] = acc[s_].y;
+                    dst[2 * SP] = acc[s_].z;
+                    dst[3 * SP] = acc[s_].w;
+                }
             }
         }
     }
     __syncthreads();
     LWS_STAMPK(17, 2);
+    // block B's depthwise weights take over the SGPRs; the round trip hides behind the pointwise step
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wdw[pass][t9][e] = dwB[t9 * 32 + 4 * (2 * wave + pass) + e];
 
-    // ---- 3. pointwise A on MFMA over the flat 16-pixel tiles of R1; epilogue BN_B + ReLU -> sA (B's input image) ----
-    const int n = lane & 15, g = lane >> 4;
+    // ---- 3. pointwise A on MFMA over the flat 16-pixel tiles of R1 (two tiles = four accumulator chains at a time);
+    //         epilogue BN_B + ReLU (zeros outside the image) -> sA = B's input image ----
     {
-        float4 aw[2][2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int k = 0; k < Cfg::TPW; k += 2) {
+            const int tile0 = wave * Cfg::TPW + k;
+            if (tile0 < Cfg::NT1) {                                  // wave-uniform
+                const bool two = (k + 1 < Cfg::TPW) && (tile0 + 1 < Cfg::NT1);
+                int p1[2];
+                float bv[2][2][4];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) aw[q][mt] = pwA[(q * 2 + mt) * 64 + lane];
-        float4 es[2], et[2];
+                for (int u = 0; u < 2; ++u) {
+                    p1[u] = (tile0 + (two ? u : 0)) * 16 + n;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            es[mt] = *reinterpret_cast<const float4 *>(bnB_s + 16 * mt + 4 * g);
-            et[mt] = *reinterpret_cast<const float4 *>(bnB_t + 16 * mt + 4 * g);
-        }
+                    for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int k = 0; k < Cfg::TPW; ++k) {
-            const int tile = wave * Cfg::TPW + k;
-            if (tile < Cfg::NT1) {                                   // wave-uniform
-                const int p1 = tile * 16 + n;
-                float4 bv[2];
+                        for (int j = 0; j < 4; ++j) bv[u][q][j] = sP[(16 * q + 4 * j + g) * SP + p1[u]];
+                }
+                floatx4 acc[2][2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) bv[q] = sB[(4 * q + g) * S1 + p1];
-                floatx4 acc[2];
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                    for (int mt = 0; mt < 2; ++mt) acc[u][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(aw[q][mt], j), f4c(bv[q], j), acc[mt], 0, 0, 0);
-                const int ry = p1 / R1X, rx = p1 - ry * R1X;
-                const int gy = t.Y0 + (ry - DB) * M, gx = t.X0 + (rx - DB) * M;
-                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                if (p1 < N1) {
+                        for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        float4 v = make_float4(bn_relu2(acc[mt][0], es[mt].x, et[mt].x), bn_relu2(acc[mt][1], es[mt].y, et[mt].y),
-                                               bn_relu2(acc[mt][2], es[mt].z, et[mt].z), bn_relu2(acc[mt][3], es[mt].w, et[mt].w));
-                        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        sA[(4 * mt + g) * S0 + p1] = v;              // channels 16 mt + 4 g .. + 3 = group 4 mt + g
+                            for (int mt = 0; mt < 2; ++mt)
+                                if (u == 0 || two)
+                                    acc[u][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(awA[q][mt], j), bv[u][q][j], acc[u][mt], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && !two) continue;
+                    const int ry = p1[u] / R1X, rx = p1[u] - ry * R1X;
+                    const int gy = t.Y0 + (ry - DB) * M, gx = t.X0 + (rx - DB) * M;
+                    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                    if (p1[u] < N1) {
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            float4 v = make_float4(bn_relu2(acc[u][mt][0], es[mt].x, et[mt].x), bn_relu2(acc[u][mt][1], es[mt].y, et[mt].y),
+                                                   bn_relu2(acc[u][mt][2], es[mt].z, et[mt].z), bn_relu2(acc[u][mt][3], es[mt].w, et[mt].w));
+                            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                            sA[(4 * mt + g) * S0 + p1[u]] = v;       // channels 16 mt + 4 g .. + 3 = group 4 mt + g
+                        }
                     }
                 }
             }
@@ -987,52 +1057,41 @@ __global__ __launch_bounds__(256) void k_ref_dws2(const float *__restrict__ in, 
     __syncthreads();
     LWS_STAMPK(17, 3);
 
-    // ---- 4. depthwise B over the tile: pixel p = (tid >> 3) + 32 i -> row (tid >> 7) + 2 i, column (tid >> 3) & 15 ----
+    // ---- 4. depthwise B over the tile: lanes = (strip of 2 rows spaced DB, column), two channel groups per wave ----
     {
-        float4 wd[9];
+        const int st_ = lane >> 4, x = lane & 15;
+        const int ry0 = (st_ % DB) + DB * Cfg::SVB * (st_ / DB);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) wd[tap] = *reinterpret_cast<const float4 *>(dwB + tap * 32 + c4 * 4);
-        const float4 *src = sA + c4 * S0 + (tid >> 7) * R1X + ((tid >> 3) & 15);
-        float *dst = reinterpret_cast<float *>(sB + (4 * q_) * S1 + (tid >> 3)) + a_;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int cg = 2 * wave + pass;
+            float4 acc[Cfg::SVB];
+            dw_vstrip<DB, Cfg::SVB>(sA + cg * S0 + ry0 * R1X + x, R1X, wdw[pass], acc);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const float4 a = src[(2 * i + kh * DB) * R1X + kw * DB];
-                    const float4 w = wd[kh * 3 + kw];
-                    acc.x = fmaf(a.x, w.x, acc.x);
-                    acc.y = fmaf(a.y, w.y, acc.y);
-                    acc.z = fmaf(a.z, w.z, acc.z);
-                    acc.w = fmaf(a.w, w.w, acc.w);
-                }
-            dst[(0 * S1 + 32 * i) * 4] = acc.x;
-            dst[(1 * S1 + 32 * i) * 4] = acc.y;
-            dst[(2 * S1 + 32 * i) * 4] = acc.z;
-            dst[(3 * S1 + 32 * i) * 4] = acc.w;
+            for (int s_ = 0; s_ < Cfg::SVB; ++s_) {
+                float *dst = sP + (4 * cg) * SP + (ry0 + DB * s_) * RT_X + x;
+                dst[0] = acc[s_].x;
+                dst[SP] = acc[s_].y;
+                dst[2 * SP] = acc[s_].z;
+                dst[3 * SP] = acc[s_].w;
+            }
         }
     }
     __syncthreads();
     LWS_STAMPK(17, 4);
 
     // ---- 5. pointwise B: wave handles tile rows 2*wave, 2*wave+1 x both output-channel tiles; store raw ----
-    float4 aw[2][2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) aw[q][mt] = pwB[(q * 2 + mt) * 64 + lane];
     floatx4 acc[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    float4 bv[2][2];
+    float bv[2][2][4];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) bv[r][q] = sB[(4 * q + g) * S1 + (2 * wave + r) * RT_X + n];
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[r][q][j] = sP[(16 * q + 4 * j + g) * SP + (2 * wave + r) * RT_X + n];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -1041,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_ref_dws2(const float *__restrict__ in, 
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(aw[q][mt], j), f4c(bv[r][q], j), acc[r][mt], 0, 0, 0);
+                    acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(awB[q][mt], j), bv[r][q][j], acc[r][mt], 0, 0, 0);
     float *outb = out + (int64_t)t.b * H * W * 32;
     const int gx = t.X0 + n * M;
 #pragma unroll

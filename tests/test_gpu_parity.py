@@ -522,6 +522,24 @@ def test_config3_kitti_crop_batch(dev, model):
     assert all(torch.equal(p1[s], p2[s][1:]) for s in range(4))
 
 
+@pytest.mark.parametrize("H,W,mdl", [(256, 512, (24, 5, 5)), (368, 1232, (24, 5, 5)), (544, 960, (32, 5, 5))])
+def test_full_size_configs_bitexact_vs_c_oracle(dev, hip_lib, H, W, mdl):
+    """One pair at the FULL sizes of BASELINE configs 2 / 4 (256x512), 1 / 3 (368x1232) and 5 (544x960, maxdisplist
+    [32,5,5]): all four stage maps equal the C oracle bit for bit (the OpenMP oracle needs a few seconds per pair on the
+    GPU box's host).  Together with test_forward_batch8_equals_single_pair_runs this pins the batch-8 runs of configs 3
+    and 4 to the oracle as well."""
+    from lwsnet_amd.models import LWSNet
+    from oracle import c_oracle as C
+    args = default_args(maxdisplist=mdl)
+    sd = make_state_dict(7, args)
+    m = LWSNet(args, device=dev).set_state_dict(sd).eval()
+    left, right = make_batch(1, H, W, 90)
+    pred = m(left, right)
+    want = C.forward(left, right, sd, mdl)
+    for s in range(4):
+        assert_bits(pred[s], want[s], f"{H}x{W} maxdisplist={mdl} stage {s + 1}")
+
+
 def test_config3_shape_vs_c_oracle_small_batch(dev, model):
     """Same ragged tiling (w/8 = 154 is not a multiple of 16, h/8 = 46 not of 4) at a size the C oracle finishes fast."""
     from oracle import c_oracle as C

@@ -28,6 +28,10 @@ from lwsnet_amd.weights import default_args, make_state_dict
 dev = torch.device('cuda:0')
 m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
 lib = ctypes.CDLL(_lib.LIB_PATH)
+if what == "dws2":
+    m.set_option("fuse_dws", 1)
+if kid == 18:
+    m.set_option("mid8_stream", 1)
 if driver == "stack":
     shape = [(B, 24, 32, 64), (B, 9, 64, 128), (B, 9, 128, 256)][arg]
     c = torch.rand(shape, device=dev) * 12
