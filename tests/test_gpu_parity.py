@@ -311,6 +311,39 @@ def test_forward_schedule_options(dev, hip_lib, plan):
         m.set_option("left_at", 1)
 
 
+def test_handles_on_their_own_threads_and_streams(dev, hip_lib):
+    """include/lwsnet_hip.h: a handle is not thread-safe, but distinct handles are independent -- three host threads, each
+    with its own handle and HIP stream (the `pipelined` mode of bench.py; ctypes releases the GIL inside lws_forward), produce
+    the single-threaded bits while their kernels overlap on the device."""
+    import threading
+    from lwsnet_amd.models import LWSNet
+    sd = make_state_dict(7)
+    left, right = make_batch(1, 256, 512, 33)
+    lt, rt = cu(left, dev), cu(right, dev)
+    models = [LWSNet(default_args(), device=dev).set_state_dict(sd).eval() for _ in range(3)]
+    ref = [p.clone() for p in models[0](lt, rt)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    bad = []
+
+    def work(i):
+        with torch.cuda.stream(streams[i]):
+            for it in range(20):
+                out = models[i](lt, rt)
+                if it % 5 == 4:
+                    streams[i].synchronize()
+                    if not all(torch.equal(a, b) for a, b in zip(out, ref)):
+                        bad.append((i, it))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    assert not bad, bad
+
+
 def test_forward_repeatable(dev, model):
     """lws_forward overlaps a side stream (refinement1_left, the feature tail) with the critical chain through events:
     back-to-back forwards without host synchronisation must reproduce the same bits (tools/soak.py runs longer)."""
