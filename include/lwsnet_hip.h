@@ -129,8 +129,9 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "fuse_shift"     1 (default) = stage-1 volume built inside the first Conv3D launch
  *   "fuse_first"     1 (default) = refinement1_disp's 1 -> 32 convolution inside its first depthwise block
  *   "defer_upsample" 1 (default) = at batches <= 2 the consumers evaluate the stage-2/3 maps
- *   "mid8_stream"    0 (default); 1 = the 8 -> 8 Conv3D layers in the d-streaming form (k_conv3d_mid8s) instead of the
- *                    3-deep tiles (k_conv3d_mid8); measured r02: equal at batch >= 2, slower at batch 1
+ *   "mid8_stream"    0 (default); 1 / 2 = the 8 -> 8 Conv3D layers in the d-streaming form (k_conv3d_mid8s, 4 / 8 waves per
+ *                    workgroup) instead of the 3-deep tiles (k_conv3d_mid8); measured r02: within +-3 % at batch >= 2,
+ *                    slower at batch 1
  *   "fuse_dws"       0 (default); 1 = consecutive depthwise-separable blocks of the refinement pairwise in one launch
  *                    (k_ref_dws2: 7 instead of 12 launches; measured r02: slower end to end at batch 1 and 8)
  * Unknown names and out-of-range values return LWS_ERR_INVALID. */

@@ -768,6 +768,8 @@ int lws_set_option(lws_handle h, const char *name, int value)
         LWS_CHECK_ARG(value == -1 || value == 0 || value == 2, "lws_set_option: left_at must be -1 (auto), 0 or 2 (got %d)", value);
     else if (strcmp(name, "split_heads") == 0)
         LWS_CHECK_ARG(value >= -1 && value <= 1, "lws_set_option: split_heads must be -1 (auto), 0 or 1 (got %d)", value);
+    else if (strcmp(name, "mid8_stream") == 0)
+        LWS_CHECK_ARG(value >= 0 && value <= 2, "lws_set_option: mid8_stream must be 0, 1 or 2 (got %d)", value);
     else
         LWS_CHECK_ARG(value == 0 || value == 1, "lws_set_option: %s must be 0 or 1 (got %d)", name, value);
     *slot = value;

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
 // then everyone computes" phase structure (profiles/r01: SQ_WAIT_INST_ANY 65 % at stage 3): only the first four planes
 // are loaded with nothing to hide behind.  39.4 KB of LDS: 4 workgroups per CU.
 // =============================================================================================
-template <int TY>
+template <int TY, int WP>
 struct Mid8sCfg {
     static constexpr int HY = TY + 2, HX = 34;
     static constexpr int NV = HY * HX;                              // voxels of one d-plane of the halo column
@@ -467,21 +467,22 @@ struct Mid8sCfg {
     static constexpr int SLOT = 8 * PS;                             // one d-plane: 8 channel planes
     static constexpr int NSLOT = 6;
     static constexpr int ITEMS = NV * 2;                            // (voxel, half) items of one d-plane
-    static constexpr int SITER = (ITEMS + 64 * TY - 1) / (64 * TY);
+    static constexpr int NT = 64 * TY * WP;
+    static constexpr int SITER = (ITEMS + NT - 1) / NT;
     static constexpr int LDS_BYTES = NSLOT * SLOT * 4;
 };
 
-template <int TY>
-__global__ __launch_bounds__(64 * TY) void k_conv3d_mid8s(const float *__restrict__ in,      // [B,D,h,w,8]
+template <int TY, int WP>
+__global__ __launch_bounds__(64 * TY * WP) void k_conv3d_mid8s(const float *__restrict__ in,      // [B,D,h,w,8]
                                                          const float *__restrict__ wpk,     // [18][64][4] A fragments
                                                          const float *__restrict__ bn_s,    // next layer BN [8]
                                                          const float *__restrict__ bn_t,
                                                          float *__restrict__ out, int D, int h, int w,
                                                          int tiles_x, int wt)
 {
-    using Cfg = Mid8sCfg<TY>;
+    using Cfg = Mid8sCfg<TY, WP>;
     constexpr int HY = Cfg::HY, HX = Cfg::HX, PS = Cfg::PS, SLOT = Cfg::SLOT, NSLOT = Cfg::NSLOT, SITER = Cfg::SITER;
-    constexpr int NT = 64 * TY;
+    constexpr int NT = Cfg::NT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
@@ -562,9 +563,10 @@ __global__ __launch_bounds__(64 * TY) void k_conv3d_mid8s(const float *__restric
     __syncthreads();
     LWS_STAMPK(18, 1);
 
-    const int rbase = g * PS + wave * HX + 2 * n;            // this wave's output row `wave` of the column; halo row = wave + kh
+    const int wrow = wave % TY, wpl = wave / TY;             // WP == 2: waves [0, TY) compute plane d, waves [TY, 2 TY) plane d + 1
+    const int rbase = g * PS + wrow * HX + 2 * n;            // this wave's output row of the column; halo row = wrow + kh
     float *outb = out + (int64_t)b * D * h * w * 8;
-    const int gx = x0 + 2 * n + xpar, gy = y0 + wave;
+    const int gx = x0 + 2 * n + xpar, gy = y0 + wrow;
 
 #pragma unroll 1
     for (int d = 0; d < D; d += 2) {
@@ -573,31 +575,51 @@ __global__ __launch_bounds__(64 * TY) void k_conv3d_mid8s(const float *__restric
         load_plane(d + 4, cc);
         const bool two = d + 1 < D;                         // wave-uniform: the last pass of an odd D computes one plane
         floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (WP == 1) {
 #pragma unroll
-        for (int kd = 0; kd < 3; ++kd) {
-            const float *p0 = lds + ((d - 1 + kd + NSLOT) % NSLOT) * SLOT + rbase;     // plane d - 1 + kd   (output plane d)
-            const float *p1 = lds + ((d + kd + NSLOT) % NSLOT) * SLOT + rbase;         // plane d + kd       (output plane d + 1)
+            for (int kd = 0; kd < 3; ++kd) {
+                const float *p0 = lds + ((d - 1 + kd + NSLOT) % NSLOT) * SLOT + rbase;     // plane d - 1 + kd   (output plane d)
+                const float *p1 = lds + ((d + kd + NSLOT) % NSLOT) * SLOT + rbase;         // plane d + kd       (output plane d + 1)
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+                for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const int step = ((kd * 3 + kh) * 4 + t) * 2 + half;
-                        const int off = half * 4 * PS + kh * HX + t;
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], p0[off], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], p1[off], acc1, 0, 0, 0);
-                    }
+                        for (int half = 0; half < 2; ++half) {
+                            const int step = ((kd * 3 + kh) * 4 + t) * 2 + half;
+                            const int off = half * 4 * PS + kh * HX + t;
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], p0[off], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], p1[off], acc1, 0, 0, 0);
+                        }
+            }
+        } else if (wpl == 0 || two) {
+            // one plane per wave: two waves per SIMD (one of each group) cover each other's LDS and MFMA latencies
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const float *p0 = lds + ((d + wpl - 1 + kd + NSLOT) % NSLOT) * SLOT + rbase;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const int step = ((kd * 3 + kh) * 4 + t) * 2 + half;
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], p0[half * 4 * PS + kh * HX + t], acc0, 0, 0, 0);
+                        }
+            }
         }
-        // epilogue of the two planes: next layer's BatchNorm + ReLU, 16-byte stores
+        // epilogue: next layer's BatchNorm + ReLU, 16-byte stores
         if (gy < h && gx < w) {
             float4 v;
-            v.x = bn_relu(acc0[0], es8.x, et8.x);
-            v.y = bn_relu(acc0[1], es8.y, et8.y);
-            v.z = bn_relu(acc0[2], es8.z, et8.z);
-            v.w = bn_relu(acc0[3], es8.w, et8.w);
-            store_act4(outb + (((int64_t)d * h + gy) * w + gx) * 8 + cb, v, wt);
-            if (two) {
+            if (WP == 1 || wpl == 0 || two) {
+                const int dd = d + (WP == 1 ? 0 : wpl);
+                v.x = bn_relu(acc0[0], es8.x, et8.x);
+                v.y = bn_relu(acc0[1], es8.y, et8.y);
+                v.z = bn_relu(acc0[2], es8.z, et8.z);
+                v.w = bn_relu(acc0[3], es8.w, et8.w);
+                store_act4(outb + (((int64_t)dd * h + gy) * w + gx) * 8 + cb, v, wt);
+            }
+            if (WP == 1 && two) {
                 v.x = bn_relu(acc1[0], es8.x, et8.x);
                 v.y = bn_relu(acc1[1], es8.y, et8.y);
                 v.z = bn_relu(acc1[2], es8.z, et8.z);
@@ -1126,13 +1148,13 @@ static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out,
     return LWS_OK;
 }
 
-template <int TY>
+template <int TY, int WP>
 static int mid8s_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w, hipStream_t st)
 {
-    using Cfg = Mid8sCfg<TY>;
+    using Cfg = Mid8sCfg<TY, WP>;
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY);
-    dim3 grid(tiles_x * tiles_y, B), block(64 * TY);
-    hipLaunchKernelGGL((k_conv3d_mid8s<TY>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w, s.layers[layer + 1].bn_s,
+    dim3 grid(tiles_x * tiles_y, B), block(Cfg::NT);
+    hipLaunchKernelGGL((k_conv3d_mid8s<TY, WP>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w, s.layers[layer + 1].bn_s,
                        s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, /*wt=*/0);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
@@ -1150,7 +1172,10 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
             // stage 3 (9 x 128 x 256) 19.1 vs 22.0 at B = 1, 31.4 vs 30.9 at B = 2, 105.7 vs 107.1 at B = 8; stage 2
             // (9 x 64 x 128) 8.8 vs 20.2 at B = 1 (64 workgroups), 32.7 vs 32.2 at B = 8; 8 x 368x1232: 371.5 vs 377.4.  Both forms
             // level off at ~77 TF useful = 103 TF issued (0.65 of the fp32-MFMA peak): the staging phases were not the limit.
-            if (s.mid8_stream > 0 && D >= 3) return mid8s_launch<4>(s, layer, act_in, act_out, B, D, h, w, st);
+            // mid8_stream = 2: 8 waves per workgroup, one plane per wave (two waves per SIMD cover each other's latencies):
+            // stage 3 19.3 at B = 1, 29.4 at B = 2, 53.9 at B = 4, 101.8 at B = 8, 379.7 at 8 x 368x1232 -- within +-3 % of the tiles.
+            if (s.mid8_stream == 1 && D >= 3) return mid8s_launch<4, 1>(s, layer, act_in, act_out, B, D, h, w, st);
+            if (s.mid8_stream == 2 && D >= 3) return mid8s_launch<4, 2>(s, layer, act_in, act_out, B, D, h, w, st);
             return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
         }
         case 16: return mid16_launch<16, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);

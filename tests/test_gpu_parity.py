@@ -103,7 +103,7 @@ def test_conv3d_stack_bitexact(dev, model, stage, shape):
     from oracle import c_oracle as C
     c = (np.random.default_rng(stage + 1).random(shape) * 12.0).astype(np.float32)
     want = C.conv3d_stack(c, model.state_dict(), stage)
-    for stream in ((0, 1) if stage > 0 else (0,)):           # 8 -> 8 layers: 3-deep tiles and the d-streaming form
+    for stream in ((0, 1, 2) if stage > 0 else (0,)):        # 8 -> 8 layers: 3-deep tiles and the two d-streaming forms
         model.set_option("mid8_stream", stream)
         try:
             got = ops.conv3d_stack(model._h, stage, cu(c, dev))

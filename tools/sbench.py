@@ -17,7 +17,7 @@ m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
 lib = _lib.load()
 for stage, (D, div) in ((1, (9, 4)), (2, (9, 2))):
     c = torch.rand((a.batch, D, H // div, W // div), device=dev) * 12
-    for stream in (0, 1):
+    for stream in (0, 1, 2):
         m.set_option("mid8_stream", stream)
         for _ in range(5):
             ops.conv3d_stack(m._h, stage, c)
