@@ -335,6 +335,19 @@ def main():
                 "traffic": None, "flop_per_launch": flop_per_launch, "avg_launch_us": round(mid["avg_us"], 2),
                 "timed_launches": int(mid_n), "timed_every_nth_step": sample_every}
 
+    # HBM-bound kernels of the path: ALGORITHMIC bytes per launch / average launch duration of the
+    # untimed breakdown pass above, against the 8 TB/s peak.  (Batch 1: latency-bound launches of a few MB.)
+    hbm = {}
+    h2, w2 = (H + 1) // 2, (W + 1) // 2
+    warp_bytes = [(2 * 16 * (h2 // 2) * (w2 // 2) + 9 * (h2 // 2) * (w2 // 2) + (h2 // 2) * (w2 // 2)) * 4 * B,
+                  (2 * 8 * h2 * w2 + 9 * h2 * w2 + h2 * w2) * 4 * B]
+    for name, nbytes in (("volume_l1_warp", sum(warp_bytes) / 2.0), ("ref_dws", 2.0 * B * H * W * 32 * 4),
+                         ("upsample_add", None), ("softargmin", (margs.maxdisplist[0] * (h2 // 4) * (w2 // 4) + H * W) * 4.0 * B)):
+        if name in kernels and nbytes:
+            gbs = nbytes / (kernels[name]["avg_us"] * 1e-6) / 1e9
+            hbm[name] = {"algorithmic_bytes_per_launch": int(nbytes), "avg_us": round(kernels[name]["avg_us"], 2),
+                         "achieved_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 4)}
+
     if rank != 0:
         if grouped:
             dist.destroy_process_group()
@@ -403,6 +416,7 @@ def main():
                    "pairs_per_gpu": B, "streams": S, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4 per step" if grouped else "single GPU",
                    "weights": "seeded synthetic (seed 7, calibrated BN)"},
         "roofline": _with_traffic(roof, B), "cpu_baseline": cpu, "latency_ms": latency, "pipelined": pipelined,
+        "hbm_kernels": hbm,
         "hot_path_kernel_ms_per_step": round(hot_ms, 4), "all_kernel_ms_per_step": round(all_ms, 4), "kernels": {k: {a: round(b, 2) for a, b in v.items()} for k, v in kernels.items()},
     }
     if grouped:
