@@ -1345,11 +1345,14 @@ template <int DA, int DB>
 static int dws2_launch(const RefDws &a, const RefDws &b, const float *in, float *out, int B, int H, int W, int M, hipStream_t st)
 {
     using Cfg = Dws2Cfg<DA, DB>;
-    static bool attr_set = false;
+    static unsigned attr_devs = 0;                     // one bit per device: the attribute is per (function, device)
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    const bool attr_set = (attr_devs >> (dev_ & 31)) & 1u;
     if (!attr_set) {
         LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ref_dws2<DA, DB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr_set = true;
+        attr_devs |= 1u << (dev_ & 31);
     }
     const int nbx = cdiv(W, RT_X * M), nby = cdiv(H, RT_Y * M);
     dim3 grid(nbx * nby * M * M * B), block(256);

@@ -1103,11 +1103,14 @@ static int mid16_launch(const Stage3d &s, int layer, const float *in, float *out
                         hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     using Cfg = Mid16Cfg<C3, TD, TY, WR, WM>;
-    static bool attr_set = false;
+    static unsigned attr_devs = 0;                     // one bit per device: the attribute is per (function, device)
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    const bool attr_set = (attr_devs >> (dev_ & 31)) & 1u;
     if (!attr_set) {
         LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3d_mid16<C3, TD, TY, WR, WM>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr_set = true;
+        attr_devs |= 1u << (dev_ & 31);
     }
     const int tiles_x = cdiv(w, 16), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
@@ -1134,11 +1137,14 @@ static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out,
                        hipStream_t st)
 {
     using Cfg = Mid8Cfg<TD, TY>;
-    static bool attr_set = false;
+    static unsigned attr_devs = 0;                     // one bit per device: the attribute is per (function, device)
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    const bool attr_set = (attr_devs >> (dev_ & 31)) & 1u;
     if (!attr_set && Cfg::LDS_BYTES > 48 * 1024) {
         LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3d_mid8<TD, TY>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr_set = true;
+        attr_devs |= 1u << (dev_ & 31);
     }
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
@@ -1192,11 +1198,14 @@ static int last_launch(const Stage3d &s, const float *act, const float *skip, fl
                        int B, int D, int h, int w, hipStream_t st)
 {
     using Cfg = LastCfg<C3, TD, TY, TX, FUSE>;
-    static bool attr_set = false;
+    static unsigned attr_devs = 0;                     // one bit per device: the attribute is per (function, device)
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    const bool attr_set = (attr_devs >> (dev_ & 31)) & 1u;
     if (!attr_set && Cfg::LDS_BYTES > 48 * 1024) {
         LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3d_last<C3, TD, TY, TX, FUSE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr_set = true;
+        attr_devs |= 1u << (dev_ & 31);
     }
     const int tiles_x = cdiv(w, TX), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
