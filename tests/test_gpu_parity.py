@@ -346,7 +346,7 @@ def test_handles_on_their_own_threads_and_streams(dev, hip_lib):
 
 def test_forward_repeatable(dev, model):
     """lws_forward overlaps a side stream (refinement1_left, the feature tail) with the critical chain through events:
-    back-to-back forwards without host synchronisation must reproduce the same bits (tools/soak.py runs longer)."""
+    back-to-back forwards without host synchronisation must reproduce the same bits."""
     for B, H, W in [(1, 256, 512), (3, 64, 256)]:
         left, right = make_batch(B, H, W, 21)
         ref = [p.clone() for p in model(left, right)]
