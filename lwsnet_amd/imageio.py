@@ -36,13 +36,20 @@ def to_input(rgb_u8):
 
 
 def jet_lut():
-    """256-entry JET colour table (RGB).  MATLAB-jet formula; cv2.COLORMAP_JET interpolates a 64-node table of the
-    same map, so individual entries may differ by a couple of levels (visual output only)."""
-    v = np.arange(256, dtype=np.float64) / 255.0
-    r = np.clip(1.5 - np.abs(4.0 * v - 3.0), 0, 1)
-    g = np.clip(1.5 - np.abs(4.0 * v - 2.0), 0, 1)
-    b = np.clip(1.5 - np.abs(4.0 * v - 1.0), 0, 1)
-    return np.stack([r, g, b], 1).__mul__(255.0).round().astype(np.uint8)
+    """OpenCV's 256-entry `COLORMAP_JET` table as RGB rows (inference.py:115 applies it; cv2.imwrite stores BGR as RGB).
+
+    OpenCV linearly interpolates a 64-node table; on the 0..255 grid that is a piecewise-linear integer ramp with
+    slope 4 per level and plateaux at 255: blue 128 -> 255 (levels 0..32), green up (32..96), red up / blue down
+    (96..160, offset by 2: (2,255,254), (6,255,250), ...), green down (160..223), red down to 128 (224..255).
+    Levels 0..127 are pinned byte for byte by the 128 distinct colours of the reference's own
+    `reference/{1..4}.png` (tests/golden/jet_reference_colours.npz, tests/test_host_cpu.py); levels 128..255 follow
+    from the table's red/blue mirror symmetry `lut[255 - i] = lut[i][::-1]`."""
+    i = np.arange(256, dtype=np.int64)
+
+    def ramp(up, down):                       # rising edge 4i+up, falling edge down-4i, clipped to a byte
+        return np.minimum(np.clip(4 * i + up, 0, 255), np.clip(down - 4 * i, 0, 255))
+
+    return np.stack([ramp(-382, 1148), ramp(-128, 892), ramp(128, 638)], 1).astype(np.uint8)
 
 
 def disparity_to_color(disp):

@@ -48,6 +48,35 @@ def test_colour_map_and_uint8_cast():
     assert np.array_equal(col[0, 1], lut[95]) and np.array_equal(col[0, 3], lut[0])   # truncation, wrap at 256
 
 
+def test_jet_table_is_opencvs_against_the_reference_pngs():
+    """The reference's own reference/{1..4}.png (written by inference.py:114-120) are the golden: every pixel is one
+    entry of cv2.COLORMAP_JET.  Fixture = their distinct colours + four raw crops (tools/make_jet_fixture.py)."""
+    from conftest import golden
+    fx = golden("jet_reference_colours.npz")
+    lut = imageio.jet_lut()
+    assert len(np.unique(lut, axis=0)) == 256                                     # injective: levels are decodable
+    index = {tuple(c): i for i, c in enumerate(lut.tolist())}
+    cols = [tuple(c) for c in fx["colours"].tolist()]
+    assert len(cols) == 128 and fx["counts"].sum() == 4 * 368 * 1232
+    assert all(c in index for c in cols), [c for c in cols if c not in index]     # every reference colour is an entry
+    levels = sorted(index[c] for c in cols)
+    assert levels == list(range(128))                                             # a gap-free ramp from level 0
+    # ramp order is the physical JET order, checked without the table: blue rises, then green, then red rises / blue falls
+    by_level = [lut[i].astype(int) for i in range(128)]
+    for a, b in zip(by_level, by_level[1:]):
+        assert (b - a).tolist() in ([0, 0, 4], [0, 0, 3], [0, 4, 0], [0, 3, 0], [2, 3, -1], [4, 0, -4]), (a, b)
+    # structure of the whole table: slope-4 piecewise-linear ramps with plateaux, endpoints, mirror symmetry
+    assert np.array_equal(lut[::-1, ::-1], lut)
+    steps = np.abs(np.diff(lut.astype(int), axis=0))
+    assert set(np.unique(steps).tolist()) <= {0, 1, 2, 3, 4} and (steps.sum(1) > 0).all()
+    assert [tuple(lut[i]) for i in (32, 96, 159, 160, 223, 224)] == \
+        [(0, 0, 255), (2, 255, 254), (254, 255, 2), (255, 252, 0), (255, 0, 0), (252, 0, 0)]
+    # raw crops of the four images: decode to levels and re-encode -> the same bytes
+    patch = fx["patch"]
+    lv = np.array([index[tuple(px)] for px in patch.reshape(-1, 3).tolist()], dtype=np.float32).reshape(patch.shape[:-1])
+    assert np.array_equal(imageio.disparity_to_color(lv), patch)
+
+
 def test_pfm_reader(tmp_path):
     data = np.arange(12, dtype="<f4").reshape(3, 4)
     with open(tmp_path / "d.pfm", "wb") as f:
