@@ -142,7 +142,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step (BASELINE config 2: 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the untimed 3-stream throughput extra")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the untimed lws_pool throughput extra")
+    ap.add_argument("--pool-workers", type=int, default=3, help="worker threads of the lws_pool extra")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent handles/HIP streams the steps rotate over (1 = every step on one stream; >1 "
                          "overlaps consecutive steps: higher pairs/s, but kernels then share CUs and their in-situ "
@@ -150,6 +151,7 @@ def main():
     ap.add_argument("--size", default="256x512", help="HxW of the synthetic pairs (default: BASELINE config 2)")
     ap.add_argument("--feature-fp16", action="store_true", help="BASELINE config 5: fp16-rounded feature maps")
     ap.add_argument("--maxdisp0", type=int, default=24, help="stage-1 hypotheses (24 = maxdisp 192, 32 = maxdisp 256)")
+    ap.add_argument("--opt", action="append", default=[], help="name=value launch-plan option (lws_set_option); experiments only")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check without a GPU: gloo, per-pair stand-in forward, value = null (tests only)")
     args = ap.parse_args()
@@ -178,6 +180,9 @@ def main():
     sd = make_state_dict(7, margs)
     S = max(1, args.streams)
     models = [LWSNet(margs, device=dev).set_state_dict(sd).eval() for _ in range(S)]
+    for o in args.opt:
+        for m in models:
+            m.set_option(o.split("=")[0], int(o.split("=")[1]))
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
     model = models[0]
     B = args.batch
@@ -219,7 +224,10 @@ def main():
     # and only on every n-th step (its begin/end events keep the next kernel from being queued behind it: ~3 us
     # of extra gap per timed launch at batch 1) -- at least ~48 timed launches with the default 50 steps.
     KC_MID16 = 3
-    sample_every = max(1, (args.steps // S) // 12)
+    # every 4th step at least: a kernel bracketed by its own events keeps its successor from being queued behind it
+    # (~3 us each at batch 1), so timing EVERY step of a short run (the driver's --steps 20) taxed the headline by 3-4 %
+    # (VERDICT r2).  20 steps -> 5 sampled steps -> 20 timed launches.
+    sample_every = max(4, (args.steps // S) // 12)
     for m in models:
         _lib.check(lib.lws_profile_enable(m._h, 1 << KC_MID16), "lws_profile_enable")
         _lib.check(lib.lws_profile_sample(m._h, sample_every), "lws_profile_sample")
@@ -247,13 +255,46 @@ def main():
         mid_ms += tot[KC_MID16]
         mid_n += cnt[KC_MID16]
     mid_avg_us = 1e3 * mid_ms / max(mid_n, 1)
+    # what the ONE collective of the path costs ("<= 3 %"): the same K steps again without the
+    # gather, same barriers, same clock -- measurable on one GPU under `torch.distributed.run --nproc-per-node 1`
+    collective_overhead = None
+    if grouped:
+        def step_plain():
+            i = counter[0] % S
+            counter[0] += 1
+            if S == 1:
+                return models[0](left, right)
+            with torch.cuda.stream(streams[i]):
+                return models[i](left, right)
+
+        def plain_steps(n):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                step_plain()
+            torch.cuda.synchronize()
+            dist.barrier()
+            return time.perf_counter() - t1
+
+        plain_steps(min(args.warmup, 3))
+        t_plain = plain_steps(args.steps)
+        tt = torch.tensor([t_plain], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_plain = float(tt.item())
+        collective_overhead = {"ms_per_step_without_gather": round(1e3 * t_plain / args.steps, 4)}
     # untimed breakdown pass: every kernel class, 10 steps
     nb = 10
+    KC_MID8 = 4
     _lib.check(lib.lws_profile_enable(model._h, -1), "lws_profile_enable")
     for _ in range(nb):
         models[0](left, right)
     torch.cuda.synchronize()
     _lib.check(lib.lws_profile_read(model._h, tot, cnt), "lws_profile_read")
+    mid8_ms = (ctypes.c_float * 4096)()
+    mid8_n = ctypes.c_int(0)
+    _lib.check(lib.lws_profile_read_class(model._h, KC_MID8, mid8_ms, 4096, ctypes.byref(mid8_n)), "lws_profile_read_class")
+    mid8_each = [mid8_ms[i] for i in range(min(mid8_n.value, 4096))]
     _lib.check(lib.lws_profile_enable(model._h, 0), "lws_profile_enable")
     # untimed latency pass: one forward at a time, host call -> result complete (SURVEY.md section 8d asks for the
     # spread as well as the mean; the throughput above keeps the stream full, this does not)
@@ -271,44 +312,33 @@ def main():
     # kernels of different forwards then share the CUs, so per-kernel durations (and roofline.frac) are not comparable.
     pipelined = None
     if not grouped and S == 1 and not args.no_pipelined:
-        P = 3
-        pm = [model] + [LWSNet(margs, device=dev).set_state_dict(sd).eval() for _ in range(P - 1)]
-        ps = [torch.cuda.Stream(device=dev) for _ in range(P)]
-        for m in pm:
-            _lib.check(lib.lws_reserve(m._h, B, H, W), "lws_reserve")
-        torch.cuda.synchronize()
-
-        import threading
-        last = [None] * P
-
-        def worker(i, n):                      # ctypes releases the GIL inside lws_forward: the host side runs P-way parallel
-            with torch.cuda.stream(ps[i]):
-                for _ in range(n):
-                    last[i] = pm[i](left, right)
-
-        def run(n):
-            ths = [threading.Thread(target=worker, args=(i, n)) for i in range(P)]
-            for t_ in ths:
-                t_.start()
-            for t_ in ths:
-                t_.join()
-
-        run(3)
-        torch.cuda.synchronize()
-        per = max(args.steps, 200)
-        kp = per * P
-        t1 = time.perf_counter()
-        run(per)
-        torch.cuda.synchronize()
-        dtp = time.perf_counter() - t1
-        pp = last[P - 1]
-        same = all(bool(torch.equal(a, b)) for a, b in zip(pp, pred))
-        pipelined = {"value": round(B * kp / dtp, 2), "unit": "pairs/s", "streams": P, "steps": kp,
-                     "ms_per_step": round(1e3 * dtp / kp, 4), "outputs_equal_single_stream": same,
-                     "what": f"{P} host threads, each issuing batch-1 forwards on its own handle / HIP stream, so that consecutive "
-                             "forwards overlap on the device (a forward costs ~345 us of host launch work and 0.51 ms on the "
-                             "device); not the headline: `value` is the single-stream number"}
-        del pm[1:]
+        P = args.pool_workers
+        per = max(args.steps, 200) * P
+        runs = []
+        same = True
+        with model.pool(workers=P) as pool:
+            pool.reserve(B, H, W)
+            outs = [[torch.empty((B, 1, H, W), device=dev) for _ in range(4)] for _ in range(2 * P)]
+            for rep in range(4):                       # first repetition = warm-up; three timed ones show the spread
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                jobs = []
+                for k in range(per):
+                    if len(jobs) >= 2 * P:
+                        jobs.pop(0).result()
+                    jobs.append(pool.submit(left, right, out=outs[k % (2 * P)]))
+                last = [j.result() for j in jobs][-1]
+                dtp = time.perf_counter() - t1
+                if rep:
+                    runs.append(B * per / dtp)
+                same = same and all(bool(torch.equal(a, b)) for a, b in zip(last, pred))
+        runs.sort()
+        pipelined = {"value": round(runs[len(runs) // 2], 2), "unit": "pairs/s", "workers": P, "steps": per,
+                     "min": round(runs[0], 2), "max": round(runs[-1], 2), "spread_pct": round(100.0 * (runs[-1] - runs[0]) / runs[len(runs) // 2], 2),
+                     "ms_per_step": round(1e3 * B / runs[len(runs) // 2], 4), "outputs_equal_single_stream": same,
+                     "what": f"lws_pool (C ABI): {P} C++ worker threads, each with a clone of the model and ONE HIP stream, keep "
+                             f"{2 * P} batch-{B} forwards in flight so that their launch-bound chains overlap on the device; median of "
+                             "3 timed repetitions; not the headline: `value` is the single-stream number"}
     if grouped:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -324,8 +354,18 @@ def main():
 
     # dominant kernel: stage-1 Conv3D c3 -> c3 (k_conv3d_mid16): 2*27*c3*c3 FLOP per voxel, voxels = B*D1*(H/8)*(W/8)
     c3 = margs.channels_3d * margs.growth_rate[0]
-    vox = B * margs.maxdisplist[0] * (H // 8) * (W // 8)
+    h2_, w2_ = (H + 1) // 2, (W + 1) // 2                    # the stem gives ceil(H/2); the hourglass halves twice more
+    vox = B * margs.maxdisplist[0] * (h2_ // 4) * (w2_ // 4)
     flop_per_launch = 2.0 * 27 * c3 * c3 * vox
+    # algorithmic FLOPs of one forward: Conv3D stacks + 2D feature extractor (both images) + refinement
+    L3 = margs.layers_3d
+    vox_s = [margs.maxdisplist[0] * (h2_ // 4) * (w2_ // 4), (2 * margs.maxdisplist[1] - 1) * (h2_ // 2) * (w2_ // 2),
+             (2 * margs.maxdisplist[2] - 1) * h2_ * w2_]
+    c3_s = [margs.channels_3d * g for g in margs.growth_rate]
+    gf_conv3d = sum(2.0 * 27 * v * (2 * c + L3 * c * c) for v, c in zip(vox_s, c3_s)) / 1e9
+    gf_feat = 0.486 * (H * W) / (256.0 * 512.0)              # 22 small layers, both images
+    gf_ref = (2.0 * 9 * 32 * 4 + 12 * 2.0 * (9 * 32 + 32 * 32) + 2.0 * 9 * 64 * 32 + 2.0 * 9 * 32) * H * W / 1e9
+    gf_pair = gf_conv3d + gf_feat + gf_ref
     mid = {"avg_us": mid_avg_us} if mid_avg_us > 0 else None
     roof = None
     if mid:
@@ -334,6 +374,31 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": None, "flop_per_launch": flop_per_launch, "avg_launch_us": round(mid["avg_us"], 2),
                 "timed_launches": int(mid_n), "timed_every_nth_step": sample_every}
+    # the whole step against the same fp32-MFMA peak: algorithmic GF of a forward x pairs / step time.  This, not `frac`,
+    # is how far the PATH is from the roofline (batch 1: 35 dependent launches, ~40 % of the step is fixed launch cost).
+    step_tf = gf_pair * B / (1e3 * elapsed / args.steps) if elapsed > 0 else 0.0      # GF per ms = TF
+    if roof:
+        roof["step_frac"] = round(step_tf / PEAK_F32_MFMA_TFLOPS, 4)
+        roof["step_achieved"] = round(step_tf, 2)
+        roof["step_gflop_per_pair"] = round(gf_pair, 3)
+    # second MFMA kernel of the path: the 8 -> 8 Conv3D layers of stages 2 and 3 (8 launches per step), from the untimed
+    # breakdown pass (events around each launch, so each carries ~1-2 us of dispatch): USEFUL FLOPs / launch time
+    secondary = None
+    if mid8_each and len(mid8_each) == 2 * L3 * nb and c3_s[1] == 8 and c3_s[2] == 8:
+        per_stage = {}
+        for si, name in ((1, "stage2"), (2, "stage3")):
+            us = [1e3 * mid8_each[k] for k in range(len(mid8_each)) if (k % (2 * L3)) // L3 == si - 1]
+            gf = 2.0 * 27 * 8 * 8 * vox_s[si] * B / 1e9
+            avg = sum(us) / len(us)
+            per_stage[name] = {"avg_launch_us": round(avg, 2), "useful_gflop_per_launch": round(gf, 4),
+                               "achieved": round(gf / avg * 1e3, 2), "frac": round(gf / avg * 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
+        tot_us = sum(1e3 * v for v in mid8_each) / nb
+        tot_gf = sum(2.0 * 27 * 64 * vox_s[si] * B * L3 for si in (1, 2)) / 1e9
+        secondary = {"kernel": "k_conv3d_mid8q<3,4>" if model.get_option("mid8_form") == 1 else "k_conv3d_mid8<3,4>",
+                     "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS,
+                     "launches_per_step": 2 * L3, "us_per_step": round(tot_us, 2),
+                     "achieved": round(tot_gf / tot_us * 1e3, 2), "frac": round(tot_gf / tot_us * 1e3 / PEAK_F32_MFMA_TFLOPS, 4), **per_stage,
+                     "note": "useful FLOPs only; event pairs around each launch (untimed pass), not kernel timestamps"}
 
     # HBM-bound kernels of the path: ALGORITHMIC bytes per launch / average launch duration of the
     # untimed breakdown pass above, against the 8 TB/s peak.  (Batch 1: latency-bound launches of a few MB.)
@@ -414,14 +479,18 @@ def main():
                                 if (H, W, args.maxdisp0) == (256, 512, 24) else
                                 f"batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[{args.maxdisp0},5,5], all 4 stages"),
                    "pairs_per_gpu": B, "streams": S, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4 per step" if grouped else "single GPU",
-                   "weights": "seeded synthetic (seed 7, calibrated BN)"},
-        "roofline": _with_traffic(roof, B), "cpu_baseline": cpu, "latency_ms": latency, "pipelined": pipelined,
+                   "weights": "seeded synthetic (seed 7, calibrated BN)", **({"options": args.opt} if args.opt else {})},
+        "roofline": _with_traffic(roof, B), "secondary": secondary, "cpu_baseline": cpu, "latency_ms": latency, "pipelined": pipelined,
         "hbm_kernels": hbm,
         "hot_path_kernel_ms_per_step": round(hot_ms, 4), "all_kernel_ms_per_step": round(all_ms, 4), "kernels": {k: {a: round(b, 2) for a, b in v.items()} for k, v in kernels.items()},
     }
     if grouped:
         out["collective"] = {"backend": dist.get_backend(), "op": "gather of stage-4 maps to rank 0, one per step, async",
                              "world": world, "rank0_slot_equals_local": gather_ok}
+        if collective_overhead:
+            base = collective_overhead["ms_per_step_without_gather"]
+            collective_overhead["overhead_pct"] = round(100.0 * (out["ms_per_step"] - base) / base, 2)
+            out["collective"].update(collective_overhead)
     print(json.dumps(out), flush=True)
     if grouped:
         dist.destroy_process_group()

@@ -10,7 +10,11 @@
  *
  * Every function returns 0 on success or a negative lws_status; the message of
  * the last failure on the calling thread is lws_last_error().
- * A handle is NOT thread-safe; use one handle per (process, device, stream).
+ * A handle is NOT thread-safe; use one handle per (process, device, stream); distinct handles may be driven from
+ * distinct host threads concurrently (lws_clone, lws_pool).
+ * A handle belongs to the HIP device that was current when lws_create ran (or lws_set_option(h, "device", n) before
+ * anything was allocated): every call that touches the GPU through it returns LWS_ERR_INVALID unless that device is the
+ * calling thread's current device.  The library never changes the caller's current device.
  */
 #ifndef LWSNET_HIP_H
 #define LWSNET_HIP_H
@@ -22,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LWS_ABI_VERSION 4
+#define LWS_ABI_VERSION 5
 
 typedef enum {
     LWS_OK = 0,
@@ -67,8 +71,9 @@ int lws_set_tensor(lws_handle h, const char *key, const float *host, const int64
  * and before any function that takes a handle + stage. */
 int lws_finalize(lws_handle h);
 
-/* Pre-allocates the activation workspace for batches up to B pairs of H x W so that
- * later calls never allocate (required before hipGraph capture). */
+/* Pre-allocates the activation workspace for batches up to B pairs of H x W and creates the handle's side streams
+ * and cross-stream events (unless option "side_streams" is 0), so that later calls allocate nothing (required before
+ * hipGraph capture). */
 int lws_reserve(lws_handle h, int B, int H, int W);
 
 /* ---- per-op entry points (each is one kernel launch) --------------------------------- */
@@ -102,20 +107,22 @@ int lws_upsample_add(const float *disp_low, const float *prev, float *out,
                      int B, int h, int w, int H, int W, void *stream);
 
 /* ---- whole path: the body of `for scale in range(3)`, models/models.py:115-156 ------ */
-/* featsL/featsR: the three feature maps of feature_extraction (1/8: [B,16,H/8,W/8],
- * 1/4: [B,16,H/4,W/4], 1/2: [B,8,H/2,W/2]).  pred_out[s] [B,1,H,W] for s = 0..2. */
+/* featsL/featsR: the three feature maps of feature_extraction.  With H2 = ceil(H/2), W2 = ceil(W/2) (the stem
+ * convolution is k3 s2 dil2 pad2, models/submodules.py:118-125; both must be divisible by 4):
+ * 1/8: [B,16,H2/4,W2/4], 1/4: [B,16,H2/2,W2/2], 1/2: [B,8,H2,W2] -- for H = 8k these are H/8, H/4, H/2, for the equally
+ * legal H = 8k-1 they are NOT floor(H/8) ... (63 rows -> 8, 16, 32).  pred_out[s] [B,1,H,W] for s = 0..2. */
 int lws_disparity_stages(lws_handle h, const float *const featsL[3], const float *const featsR[3],
                          int B, int H, int W, float *const pred_out[3], void *stream);
 
 /* ---- the 2D networks around the path ---------- */
 /* feature_extraction, models/submodules.py:113-188 (+ hourglass :35-109): img [N,3,H,W] ->
- * f8 [N,16,H/8,W/8], f4 [N,16,H/4,W/4], f2 [N,8,H/2,W/2]. */
+ * f8 [N,16,H2/4,W2/4], f4 [N,16,H2/2,W2/2], f2 [N,8,H2,W2] with H2 = ceil(H/2), W2 = ceil(W/2) as above. */
 int lws_feature_extraction(lws_handle h, const float *img, int N, int H, int W, float *f8, float *f4, float *f2,
                            void *stream);
 
 /* models/models.py:158-162 with refinement1/refinement2, models/submodules.py:223-327:
  * pred4 = pred3 + refinement2(concat(refinement1_left(left), refinement1_disp(pred3))).
- * left [B,3,H,W]; pred3, pred4 [B,1,H,W]. */
+ * left [B,3,H,W]; pred3, pred4 [B,1,H,W].  Any H, W > 0 (the refinement has no stride, hence no size rule). */
 int lws_refine(lws_handle h, const float *left, const float *pred3, int B, int H, int W, float *pred4, void *stream);
 
 /* LWSNet.forward, models/models.py:106-164: left, right [B,3,H,W] -> pred_out[0..3] [B,1,H,W]. */
@@ -129,11 +136,14 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "fuse_shift"     1 (default) = stage-1 volume built inside the first Conv3D launch
  *   "fuse_first"     1 (default) = refinement1_disp's 1 -> 32 convolution inside its first depthwise block
  *   "defer_upsample" 1 (default) = at batches <= 2 the consumers evaluate the stage-2/3 maps
- *   "mid8_stream"    0 (default); 1 / 2 = the 8 -> 8 Conv3D layers in the d-streaming form (k_conv3d_mid8s, 4 / 8 waves per
- *                    workgroup) instead of the 3-deep tiles (k_conv3d_mid8); measured r02: within +-3 % at batch >= 2,
- *                    slower at batch 1
- *   "fuse_dws"       0 (default); 1 = consecutive depthwise-separable blocks of the refinement pairwise in one launch
- *                    (k_ref_dws2: 7 instead of 12 launches; measured r02: slower end to end at batch 1 and 8)
+ *   "mid8_form"      the 8 -> 8 Conv3D layers (stages 2, 3): 0 = v_mfma_f32_16x16x4_f32 with rows = (x parity, cout)
+ *                    (k_conv3d_mid8: 25 % of every instruction is structural zero padding), 1 = v_mfma_f32_4x4x1_16B_f32
+ *                    with the A block broadcast (k_conv3d_mid8q: 4 couts x 64 voxels per instruction, no padding)
+ *   "side_streams"   1 (default) = refinement1_left and the feature-extractor tail run on handle-owned side streams;
+ *                    0 = the whole forward on the caller's stream, no forks / joins (what lws_pool workers use)
+ *   "ref_order"      block -> tile order of the phase-grid refinement kernels: 0 = dispatch order, 1 = XCD-contiguous,
+ *                    2 = XCD-contiguous with the dilation phase slowest
+ *   "device"         the HIP device the handle belongs to; settable only before lws_finalize / lws_reserve allocate
  * Unknown names and out-of-range values return LWS_ERR_INVALID. */
 int lws_set_option(lws_handle h, const char *name, int value);
 int lws_get_option(lws_handle h, const char *name, int *value);
@@ -168,7 +178,41 @@ int lws_profile_sample(lws_handle h, int every_n);
 /* Synchronises the recorded events and returns, per kernel class, the summed device time in
  * milliseconds and the number of launches.  Both arrays have LWS_KC_COUNT entries. */
 int lws_profile_read(lws_handle h, double *total_ms, int64_t *launches);
+/* The individual launches of one kernel class, in launch order: ms_out[0 .. min(*count, capacity)) receives their
+ * durations in milliseconds, *count the number of recorded launches (bench.py separates the stage-2 from the stage-3
+ * launches of k_conv3d_mid8 with it). */
+int lws_profile_read_class(lws_handle h, int kernel_class, float *ms_out, int capacity, int *count);
 const char *lws_kernel_class_name(int kernel_class);
+
+/* ---- several forwards in flight (no counterpart in the reference: inference.py:105-109 is one thread, one stream) ---- */
+/* A second handle for the same model on the same device: shares src's (read-only) parameter slab, owns its workspace,
+ * streams and options.  src must outlive it and must not be re-finalized while clones exist; a clone refuses
+ * lws_set_tensor / lws_finalize.  Use: one clone per host thread / stream. */
+int lws_clone(lws_handle src, lws_handle *out);
+
+/* A pool of `workers` host threads, each with its own clone of `model` and ONE HIP stream.  A batch-1 forward is a chain
+ * of ~35 dependent launches (launch-latency-bound, ~345 us of host time to issue); the pool keeps `workers` of them in
+ * flight so that they overlap on the device and their host cost runs in parallel.  Results are bit-identical to
+ * lws_forward.  flags: 0, or LWS_POOL_SIDE_STREAMS to let every worker also use its per-handle side streams
+ * (3 streams per worker; more streams than hardware queues makes throughput depend on the stream -> queue mapping).
+ * `model` must outlive the pool. */
+typedef struct lws_pool *lws_pool_handle;
+#define LWS_POOL_SIDE_STREAMS 1
+int lws_pool_create(lws_handle model, int workers, int flags, lws_pool_handle *out);
+int lws_pool_destroy(lws_pool_handle p);            /* runs what is queued, then joins the workers */
+int lws_pool_workers(lws_pool_handle p);
+/* Pre-allocates every worker's workspace (waits for the jobs in flight first). */
+int lws_pool_reserve(lws_pool_handle p, int B, int H, int W);
+/* Queues one lws_forward(left, right -> pred_out[0..3]) and returns its ticket.  The job starts behind everything
+ * already queued on `after_stream` (the stream that produces left / right; NULL = the default stream).  The buffers
+ * must stay valid, and pred_out unread, until lws_pool_wait(ticket) has returned.  At most 4 x workers jobs are kept
+ * in flight: a further submit first waits for the oldest one.  Thread-safe. */
+int lws_pool_submit(lws_pool_handle p, const float *left, const float *right, int B, int H, int W,
+                    float *const pred_out[4], void *after_stream, int64_t *ticket);
+/* Blocks the calling thread until the job's outputs are complete in device memory; returns the job's status
+ * (lws_last_error() then holds the worker's message).  A ticket may be waited for any number of times. */
+int lws_pool_wait(lws_pool_handle p, int64_t ticket);
+int lws_pool_wait_all(lws_pool_handle p);
 
 #ifdef __cplusplus
 }

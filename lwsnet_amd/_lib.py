@@ -47,8 +47,18 @@ PROTOTYPES = {
     "lws_profile_enable": (_i, [_vp, _i]),
     "lws_profile_sample": (_i, [_vp, _i]),
     "lws_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), c_int64_p]),
+    "lws_profile_read_class": (_i, [_vp, _i, c_float_p, _i, ctypes.POINTER(_i)]),
     "lws_kernel_class_name": (ctypes.c_char_p, [_i]),
+    "lws_clone": (_i, [_vp, ctypes.POINTER(_vp)]),
+    "lws_pool_create": (_i, [_vp, _i, _i, ctypes.POINTER(_vp)]),
+    "lws_pool_destroy": (_i, [_vp]),
+    "lws_pool_workers": (_i, [_vp]),
+    "lws_pool_reserve": (_i, [_vp, _i, _i, _i]),
+    "lws_pool_submit": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp * 4, _vp, c_int64_p]),
+    "lws_pool_wait": (_i, [_vp, ctypes.c_int64]),
+    "lws_pool_wait_all": (_i, [_vp]),
 }
+LWS_POOL_SIDE_STREAMS = 1
 LWS_KC_COUNT = 13
 
 _lib = None
@@ -73,7 +83,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lws_abi_version() != 4:
+    if lib.lws_abi_version() != 5:
         raise RuntimeError("liblwsnet_hip.so ABI version mismatch; rebuild the extension")
     _lib = lib
     return lib

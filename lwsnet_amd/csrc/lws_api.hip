@@ -96,7 +96,7 @@ static void fold_bn(const lws_ctx *h, const std::string &p, std::vector<float> &
 struct WsLayout {
     size_t act_a, act_b, cost_raw, cost_out, low[3], total;   // float offsets (hot path); low[s]: stage s low-res disparity
     // 2D networks: feature-extractor maps for N = 2B images, refinement ping-pong maps
-    size_t fe_a0, fe_o, fe_a2, fe_o2, fe_c1, fe_pre, fe_c3, fe_f8, fe_f4, fe_o3, fe_cls, fe_f2;
+    size_t fe_o, fe_o2, fe_pre, fe_f8, fe_f4, fe_o3, fe_cls, fe_f2;
     size_t r_a, r_b, r_c;
     size_t total_all;
 };
@@ -138,13 +138,9 @@ static WsLayout ws_layout(const lws_ctx *h, int B, int H, int W)
     L.total = L.low[2] + al((size_t)B * p2);
     size_t o = L.total;
     auto take = [&](size_t n) { size_t r = o; o += al(n); return r; };
-    L.fe_a0 = take(N * 4 * p2);
     L.fe_o = take(N * 8 * p2);
-    L.fe_a2 = take(N * 4 * p2);
     L.fe_o2 = take(N * 8 * p2);
-    L.fe_c1 = take(N * 16 * p4);
     L.fe_pre = take(N * 16 * p4);
-    L.fe_c3 = take(N * 16 * p8);
     L.fe_f8 = take(N * 16 * p8);
     L.fe_f4 = take(N * 16 * p4);
     L.fe_o3 = take(N * 8 * p2);
@@ -440,8 +436,7 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
     const Net2d &n = h->net2d;
     const int N = nA + nB, H2 = half_up(H), W2 = half_up(W), H4 = H2 / 2, W4 = W2 / 2, H8 = H2 / 4, W8 = W2 / 4;
     float *ws = h->ws;
-    float *a0 = ws + L.fe_a0, *o = ws + L.fe_o, *a2 = ws + L.fe_a2, *o2 = ws + L.fe_o2, *c1 = ws + L.fe_c1,
-          *pre = ws + L.fe_pre, *c3 = ws + L.fe_c3;
+    float *o = ws + L.fe_o, *o2 = ws + L.fe_o2, *pre = ws + L.fe_pre;
     int rc;
 #define LWS_FE(call)                                   \
     {                                                  \
@@ -461,7 +456,7 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
         LWS_FE(launch_conv2d_pair(n.fe[6], n.fe[7], pre + 16 * q4, nullptr, f8 + 16 * q8, cnt, H4, W4, st));     // conv3, conv4 -> f8
         return LWS_OK;
     };
-    if (tail != nullptr && split_heads(h, nB) && h->side2 != nullptr) {
+    if (tail != nullptr && tail != st && split_heads(h, nB) && h->side2 != nullptr) {
         // left and right images are independent up to the cost volume: for batches >= 4 pairs the right images'
         // layers run on a second side stream and join before f8 is consumed (measured r01: +4 % at B = 8, but
         // -11 % at B = 1, where the two half-size launches only add dispatch overhead: there they stay batched)
@@ -525,14 +520,6 @@ static int refine_left(lws_ctx *h, const float *left, int B, int H, int W, const
     const Net2d &n = h->net2d;
     float *ra = h->ws + L.r_a, *rc_ = h->ws + L.r_c;
     int rc;
-    if (h->opt.fuse_dws && ref_dws_pair_can_fuse(n.r1[0][0], n.r1[0][1]) && ref_dws_pair_can_fuse(n.r1[0][2], n.r1[0][3])) {
-        // blocks (dil 2, 4) and (dil 8, 16) pairwise in one launch each: 3 launches instead of 5, result in r_a
-        LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(left, 3, n.r1_first[0], rc_, B, H, W, st));
-        float *rb = h->ws + L.r_b;      // free until refine_rest, which runs after this branch has joined
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws_pair(n.r1[0][0], n.r1[0][1], rc_, rb, B, H, W, st));
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws_pair(n.r1[0][2], n.r1[0][3], rb, ra, B, H, W, st));
-        return LWS_OK;
-    }
     LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(left, 3, n.r1_first[0], ra, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][0], ra, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][1], rc_, ra, B, H, W, st));
@@ -576,25 +563,14 @@ static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLa
         LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][0], rb, rc_, B, H, W, st));
     }
     // refinement1_disp blocks 2..4 (dil 4, 8, 16; block 1 ran above): rc_ -> ... -> rb
-    if (h->opt.fuse_dws && ref_dws_pair_can_fuse(n.r1[1][1], n.r1[1][2])) {
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws_pair(n.r1[1][1], n.r1[1][2], rc_, rb, B, H, W, st));     // dil 4, 8
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][3], rb, rc_, B, H, W, st));                       // dil 16
-        std::swap(rb, rc_);
-    } else {
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][1], rc_, rb, B, H, W, st));
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][2], rb, rc_, B, H, W, st));
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][3], rc_, rb, B, H, W, st));
-    }
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][1], rc_, rb, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][2], rb, rc_, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][3], rc_, rb, B, H, W, st));
     LWS_RF(LWS_KC_REF_CONV64, launch_ref_conv64(n.r2_first, ra, rb, rc_, B, H, W, st));
-    if (h->opt.fuse_dws && ref_dws_pair_can_fuse(n.r2[0], n.r2[1]) && ref_dws_pair_can_fuse(n.r2[2], n.r2[3])) {
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws_pair(n.r2[0], n.r2[1], rc_, ra, B, H, W, st));             // dil 8, 4
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws_pair(n.r2[2], n.r2[3], ra, rc_, B, H, W, st));             // dil 2, 1
-    } else {
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[0], rc_, ra, B, H, W, st));
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[1], ra, rc_, B, H, W, st));
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[2], rc_, ra, B, H, W, st));
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[3], ra, rc_, B, H, W, st));
-    }
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[0], rc_, ra, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[1], ra, rc_, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[2], rc_, ra, B, H, W, st));
+    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[3], ra, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_LAST, launch_ref_last(rc_, n.r2_last, pred3, pred4, B, H, W, st));
     return LWS_OK;
 }
@@ -703,6 +679,45 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
 
 }  // namespace lws
 
+// Every entry point that touches the GPU through a handle requires the calling thread's current HIP device to be the
+// handle's (recorded by lws_create, or set with lws_set_option("device")): its parameter slab, workspace, streams and
+// events live there, and a launch from another device would run on foreign pointers.  Checked, never switched: a C
+// library that silently changes the caller's current device is worse than one that refuses.
+static int check_device(const lws_ctx *h, const char *what)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) {
+        (void)hipGetLastError();
+        cur = -1;
+    }
+    if (cur != h->device) {
+        set_error("%s: the handle belongs to HIP device %d but the calling thread's current device is %d "
+                  "(hipSetDevice(%d) first; -1 = no device)", what, h->device, cur, h->device);
+        return LWS_ERR_INVALID;
+    }
+    return LWS_OK;
+}
+#define LWS_CHECK_DEVICE(h, what)              \
+    do {                                       \
+        int rc_dev_ = check_device((h), what); \
+        if (rc_dev_) return rc_dev_;           \
+    } while (0)
+
+// side streams and cross-stream events of lws_forward: created by lws_reserve (which promises that later calls allocate
+// nothing) or, for callers that never reserve, on the first forward
+static int ensure_streams(lws_ctx *h)
+{
+    if (h->side) return LWS_OK;
+    const unsigned ef = hipEventDisableTiming | hipEventDisableSystemFence;
+    LWS_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    LWS_HIP(hipEventCreateWithFlags(&h->ev_fork, ef));
+    LWS_HIP(hipEventCreateWithFlags(&h->ev_join, ef));
+    for (int i = 0; i < 3; ++i) LWS_HIP(hipEventCreateWithFlags(&h->ev_feat[i], ef));
+    LWS_HIP(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+    LWS_HIP(hipEventCreateWithFlags(&h->ev_right, ef));
+    return LWS_OK;
+}
+
 extern "C" {
 
 int lws_abi_version(void) { return LWS_ABI_VERSION; }
@@ -745,6 +760,17 @@ int lws_create(const lws_config *cfg, lws_handle *out)
     return LWS_OK;
 }
 
+// copies the per-handle options into the per-layer structs the launchers read
+static void apply_options(lws_ctx *h)
+{
+    for (int i = 0; i < 3; ++i) h->stage[i].mid8_form = h->opt.mid8_form;
+    lws::Net2d &n = h->net2d;
+    for (int k = 0; k < 2; ++k)
+        for (int b = 0; b < 4; ++b) n.r1[k][b].order = h->opt.ref_order;
+    for (int b = 0; b < 4; ++b) n.r2[b].order = h->opt.ref_order;
+    n.r2_first.order = h->opt.ref_order;
+}
+
 static int *option_slot(lws_ctx *h, const char *name)
 {
     struct { const char *name; int *slot; } tab[] = {{"left_at", &h->opt.left_at},
@@ -752,8 +778,10 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"fuse_shift", &h->opt.fuse_shift},
                                                      {"fuse_first", &h->opt.fuse_first},
                                                      {"defer_upsample", &h->opt.defer_upsample},
-                                                     {"fuse_dws", &h->opt.fuse_dws},
-                                                     {"mid8_stream", &h->opt.mid8_stream}};
+                                                     {"side_streams", &h->opt.side_streams},
+                                                     {"ref_order", &h->opt.ref_order},
+                                                     {"device", &h->device},
+                                                     {"mid8_form", &h->opt.mid8_form}};
     for (auto &e : tab)
         if (strcmp(e.name, name) == 0) return e.slot;
     return nullptr;
@@ -768,12 +796,18 @@ int lws_set_option(lws_handle h, const char *name, int value)
         LWS_CHECK_ARG(value == -1 || value == 0 || value == 2, "lws_set_option: left_at must be -1 (auto), 0 or 2 (got %d)", value);
     else if (strcmp(name, "split_heads") == 0)
         LWS_CHECK_ARG(value >= -1 && value <= 1, "lws_set_option: split_heads must be -1 (auto), 0 or 1 (got %d)", value);
-    else if (strcmp(name, "mid8_stream") == 0)
-        LWS_CHECK_ARG(value >= 0 && value <= 2, "lws_set_option: mid8_stream must be 0, 1 or 2 (got %d)", value);
+    else if (strcmp(name, "ref_order") == 0)
+        LWS_CHECK_ARG(value >= 0 && value <= 2, "lws_set_option: ref_order must be 0, 1 or 2 (got %d)", value);
+    else if (strcmp(name, "device") == 0) {
+        LWS_CHECK_ARG(value >= 0, "lws_set_option: device must be >= 0 (got %d)", value);
+        LWS_CHECK_ARG(h->params == nullptr && h->ws == nullptr && h->side == nullptr,
+                      "lws_set_option: the device of a handle can only be changed before lws_finalize / lws_reserve "
+                      "have allocated on device %d", h->device);
+    }
     else
         LWS_CHECK_ARG(value == 0 || value == 1, "lws_set_option: %s must be 0 or 1 (got %d)", name, value);
     *slot = value;
-    for (int i = 0; i < 3; ++i) h->stage[i].mid8_stream = h->opt.mid8_stream;
+    apply_options(h);
     return LWS_OK;
 }
 
@@ -807,6 +841,7 @@ int lws_profile_sample(lws_handle h, int every_n)
 int lws_profile_read(lws_handle h, double *total_ms, int64_t *launches)
 {
     LWS_CHECK_ARG(h && total_ms && launches, "lws_profile_read: null argument");
+    LWS_CHECK_DEVICE(h, "lws_profile_read");
     for (int i = 0; i < LWS_KC_COUNT; ++i) {
         total_ms[i] = 0.0;
         launches[i] = 0;
@@ -818,6 +853,26 @@ int lws_profile_read(lws_handle h, double *total_ms, int64_t *launches)
         total_ms[r.kc] += ms;
         launches[r.kc] += 1;
     }
+    return LWS_OK;
+}
+
+int lws_profile_read_class(lws_handle h, int kernel_class, float *ms_out, int capacity, int *count)
+{
+    LWS_CHECK_ARG(h && count && (ms_out || capacity == 0) && capacity >= 0, "lws_profile_read_class: bad argument");
+    LWS_CHECK_ARG(kernel_class >= 0 && kernel_class < LWS_KC_COUNT, "lws_profile_read_class: unknown kernel class %d", kernel_class);
+    LWS_CHECK_DEVICE(h, "lws_profile_read_class");
+    int n = 0;
+    for (lws_prof_rec &r : h->prof) {
+        if (r.kc != kernel_class) continue;
+        if (n < capacity) {
+            LWS_HIP(hipEventSynchronize(r.t1));
+            float ms = 0.f;
+            LWS_HIP(hipEventElapsedTime(&ms, r.t0, r.t1));
+            ms_out[n] = ms;
+        }
+        ++n;
+    }
+    *count = n;
     return LWS_OK;
 }
 
@@ -845,7 +900,7 @@ int lws_destroy(lws_handle h)
         (void)hipStreamDestroy(h->side2);
         (void)hipEventDestroy(h->ev_right);
     }
-    if (h->params) (void)hipFree(h->params);
+    if (h->params && h->owns_params) (void)hipFree(h->params);
     if (h->ws) (void)hipFree(h->ws);
     delete h;
     return LWS_OK;
@@ -854,6 +909,10 @@ int lws_destroy(lws_handle h)
 int lws_set_tensor(lws_handle h, const char *key, const float *host, const int64_t *shape, int ndim)
 {
     LWS_CHECK_ARG(h && key && host && shape && ndim >= 1 && ndim <= 5, "lws_set_tensor: bad argument");
+    if (!h->owns_params) {
+        set_error("lws_set_tensor: this handle is a clone and shares its source's parameters");
+        return LWS_ERR_STATE;
+    }
     auto it = h->spec.find(key);
     LWS_CHECK_ARG(it != h->spec.end(), "set_state_dict: unexpected key '%s'", key);
     std::vector<int64_t> shp(shape, shape + ndim);
@@ -875,6 +934,11 @@ int lws_set_tensor(lws_handle h, const char *key, const float *host, const int64
 int lws_finalize(lws_handle h)
 {
     LWS_CHECK_ARG(h, "lws_finalize: null handle");
+    if (!h->owns_params) {
+        set_error("lws_finalize: this handle is a clone (lws_clone / lws_pool worker) and shares its source's parameters");
+        return LWS_ERR_STATE;
+    }
+    LWS_CHECK_DEVICE(h, "lws_finalize");
     const int L = h->cfg.layers_3d + 2;
     // every hot-path tensor must be present
     for (int i = 0; i < 3; ++i)
@@ -954,6 +1018,7 @@ int lws_finalize(lws_handle h)
         }
     }
     if (h->have_2d) bind_net2d(h, o2d);
+    apply_options(h);
     h->finalized = true;
     return LWS_OK;
 }
@@ -963,6 +1028,11 @@ int lws_reserve(lws_handle h, int B, int H, int W)
     LWS_CHECK_ARG(h, "lws_reserve: null handle");
     int rc = check_size(h, B, H, W);
     if (rc) return rc;
+    LWS_CHECK_DEVICE(h, "lws_reserve");
+    if (h->opt.side_streams != 0) {      // (single-stream plans never fork)
+        rc = ensure_streams(h);
+        if (rc) return rc;
+    }
     return ensure_ws(h, ws_layout(h, B, H, W).total_all);
 }
 
@@ -990,6 +1060,7 @@ int lws_conv3d_stack(lws_handle h, int stage, const float *cost_in, float *cost_
     LWS_CHECK_ARG(h && cost_in && cost_out && cost_in != cost_out, "conv3d_stack: bad pointer");
     LWS_CHECK_ARG(stage >= 0 && stage < 3, "conv3d_stack: stage must be 0..2 (got %d)", stage);
     LWS_CHECK_ARG(B >= 1 && D >= 1 && hh >= 1 && ww >= 1, "conv3d_stack: bad shape");
+    LWS_CHECK_DEVICE(h, "lws_conv3d_stack");
     if (!h->finalized) {
         set_error("conv3d_stack: lws_finalize has not been called");
         return LWS_ERR_STATE;
@@ -1023,6 +1094,7 @@ int lws_disparity_stages(lws_handle h, const float *const featsL[3], const float
         LWS_CHECK_ARG(featsL[s] && featsR[s] && pred_out[s], "disparity_stages: null tensor for stage %d", s);
     int rc = check_size(h, B, H, W);
     if (rc) return rc;
+    LWS_CHECK_DEVICE(h, "lws_disparity_stages");
     if (!h->finalized) {
         set_error("disparity_stages: lws_finalize has not been called");
         return LWS_ERR_STATE;
@@ -1039,6 +1111,7 @@ int lws_feature_extraction(lws_handle h, const float *img, int N, int H, int W, 
     LWS_CHECK_ARG(h && img && f8 && f4 && f2, "feature_extraction: null pointer");
     LWS_CHECK_ARG(N >= 1 && H > 0 && W > 0 && half_up(H) % 4 == 0 && half_up(W) % 4 == 0,
                   "feature_extraction: unsupported size N=%d %dx%d (ceil(H/2), ceil(W/2) divisible by 4)", N, H, W);
+    LWS_CHECK_DEVICE(h, "lws_feature_extraction");
     if (!h->finalized || !h->have_2d) {
         set_error("feature_extraction: the 2D network tensors were not all set before lws_finalize");
         return LWS_ERR_STATE;
@@ -1054,6 +1127,7 @@ int lws_refine(lws_handle h, const float *left, const float *pred3, int B, int H
 {
     LWS_CHECK_ARG(h && left && pred3 && pred4, "refine: null pointer");
     LWS_CHECK_ARG(B >= 1 && H > 0 && W > 0, "refine: unsupported size B=%d %dx%d", B, H, W);
+    LWS_CHECK_DEVICE(h, "lws_refine");
     if (!h->finalized || !h->have_2d) {
         set_error("refine: the 2D network tensors were not all set before lws_finalize");
         return LWS_ERR_STATE;
@@ -1073,6 +1147,7 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     for (int s = 0; s < 4; ++s) LWS_CHECK_ARG(pred_out[s], "forward: null output for stage %d", s + 1);
     int rc = check_size(h, B, H, W);
     if (rc) return rc;
+    LWS_CHECK_DEVICE(h, "lws_forward");
     if (!h->finalized || !h->have_2d) {
         set_error("forward: set_state_dict/lws_finalize must be called with the full state dict first");
         return LWS_ERR_STATE;
@@ -1087,16 +1162,16 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
         ~MaskGuard() { h->prof_mask = h->prof_mask_cfg; }
     } mask_guard{h};
     h->prof_mask = (h->prof_every <= 1 || h->prof_calls++ % (unsigned)h->prof_every == 0) ? h->prof_mask_cfg : 0u;
-    // refinement1_left depends on the left image only: it runs on a side stream, concurrently with the feature
-    // extractor and the three volume stages, and joins before the rest of the refinement (speed only).
-    if (!h->side) {
-        LWS_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-        LWS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
-        LWS_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
-        for (int i = 0; i < 3; ++i) LWS_HIP(hipEventCreateWithFlags(&h->ev_feat[i], hipEventDisableTiming | hipEventDisableSystemFence));
-        LWS_HIP(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
-        LWS_HIP(hipEventCreateWithFlags(&h->ev_right, hipEventDisableTiming | hipEventDisableSystemFence));
+    // Two independent branches run on handle-owned side streams (speed only): refinement1_left, which depends on the
+    // left image only, and the tail of the feature extractor.  Option "side_streams" = 0 keeps everything on the caller's
+    // stream: no forks, joins or event bubbles -- the plan lws_pool uses, where the kernels of OTHER forwards fill the CUs
+    // and three streams map onto three hardware queues instead of nine onto four.
+    const bool multi = h->opt.side_streams != 0;
+    if (multi) {
+        rc = ensure_streams(h);
+        if (rc) return rc;
     }
+    hipStream_t side = multi ? h->side : st;
     // refinement1_left (5 kernels, 58 us of HBM-bound work at batch 1) depends on the left image only.  Small batches
     // run it on the side stream beside stages 2 and 3, whose MFMA kernels keep their weights in registers and do not
     // mind; beside the feature head it spilled into stage 1, where k_conv3d_mid16's weight stream from L2 does mind
@@ -1106,15 +1181,15 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     // ev_fork orders both side streams behind everything already queued on st (the previous forward's readers of the
     // buffers they overwrite, the producers of left/right): recorded whenever either consumer of it runs -- the early
     // refinement1_left below or the right-image feature head on side2 (feature_extraction, batches >= 4)
-    if (left_at == 0 || split_heads(h, B)) LWS_HIP(hipEventRecord(h->ev_fork, st));
+    if (multi && (left_at == 0 || split_heads(h, B))) LWS_HIP(hipEventRecord(h->ev_fork, st));
     if (left_at == 0) {
-        LWS_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        rc = refine_left(h, left, B, H, W, L, h->side);                                     // models.py:158
+        if (multi) LWS_HIP(hipStreamWaitEvent(side, h->ev_fork, 0));
+        rc = refine_left(h, left, B, H, W, L, side);                                        // models.py:158
         if (rc) return rc;
-        LWS_HIP(hipEventRecord(h->ev_join, h->side));
+        if (multi) LWS_HIP(hipEventRecord(h->ev_join, side));
     }
     float *f8 = h->ws + L.fe_f8, *f4 = h->ws + L.fe_f4, *f2 = h->ws + L.fe_f2;
-    rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st, h->side, h->ev_feat);   // models.py:110-111
+    rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st, side, h->ev_feat);       // models.py:110-111
     if (rc) return rc;
     const size_t n2 = (size_t)B * 8 * half_up(H) * half_up(W), n4 = n2 / 2, n8 = n2 / 8;   // 8 / 16 / 16 channels
     const float *fl[3] = {f8, f4, f2};
@@ -1123,27 +1198,31 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     // stage 1's Conv3D stack: it overlaps with stage 1's regression and with stage 2 instead of competing with the
     // MFMA-bound stage-1 kernels for the CUs.
     // (conv5 -> f4 is one short kernel: it goes to the side stream at once, so stage 2 never waits for it.)
-    LWS_HIP(hipEventRecord(h->ev_feat[0], st));
-    LWS_HIP(hipStreamWaitEvent(h->side, h->ev_feat[0], 0));
-    rc = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, h->side, h->ev_feat, 1);
+    if (multi) {
+        LWS_HIP(hipEventRecord(h->ev_feat[0], st));
+        LWS_HIP(hipStreamWaitEvent(side, h->ev_feat[0], 0));
+    }
+    rc = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, 1);
     if (rc) return rc;
     auto launch_tail = [&]() -> int {
-        LWS_HIP(hipEventRecord(h->ev_feat[0], st));
-        LWS_HIP(hipStreamWaitEvent(h->side, h->ev_feat[0], 0));
-        int r2 = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, h->side, h->ev_feat, 2);
+        if (multi) {
+            LWS_HIP(hipEventRecord(h->ev_feat[0], st));
+            LWS_HIP(hipStreamWaitEvent(side, h->ev_feat[0], 0));
+        }
+        int r2 = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, 2);
         if (r2) return r2;
         if (left_at == 2) {
-            r2 = refine_left(h, left, B, H, W, L, h->side);
+            r2 = refine_left(h, left, B, H, W, L, side);
             if (r2) return r2;
-            LWS_HIP(hipEventRecord(h->ev_join, h->side));
+            if (multi) LWS_HIP(hipEventRecord(h->ev_join, side));
         }
         return LWS_OK;
     };
     DeferState ds;
     ds.allow_last = refine_can_defer(h);
-    rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st, h->ev_feat, launch_tail, &ds);     // :115-156
+    rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st, multi ? h->ev_feat : nullptr, launch_tail, &ds);   // :115-156
     if (rc) return rc;
-    LWS_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    if (multi) LWS_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     return refine_rest(h, pred_out[2], B, H, W, L, pred_out[3], st, &ds, pred_out[1]);       // :159-162
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -35,6 +36,20 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, device).  One mask per launch site, one bit per
+// device; handles on different host threads reach a launch site concurrently (lws_pool, bench.py's pipelined mode), so the
+// mask is atomic -- a lost race only repeats the idempotent call.  Devices >= 64 set the attribute on every launch.
+static inline int ensure_dyn_lds(std::atomic<uint64_t> &done, const void *fn, int bytes)
+{
+    int dev = 0;
+    LWS_HIP(hipGetDevice(&dev));
+    const uint64_t bit = dev >= 0 && dev < 64 ? (uint64_t)1 << dev : 0;
+    if (bit != 0 && (done.load(std::memory_order_acquire) & bit)) return LWS_OK;
+    LWS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (bit != 0) done.fetch_or(bit, std::memory_order_release);
+    return LWS_OK;
+}
+
 // 16-byte activation store.  wt (wave-uniform) selects a write-through store (sc0 sc1): the line does not stay dirty in
 // the XCD's L2, so the end-of-kernel release has less to write back.  Measured r01 on MI355X in k_ref_dws: 12.5 -> 11.7 us
 // per launch at B = 1 (16.8 MB written) but 78.7 -> 95.8 us at B = 8 (134 MB), so launchers enable it for small outputs only.
@@ -56,7 +71,7 @@ static inline int use_wt_stores(size_t out_bytes) { return out_bytes <= ((size_t
 // Diagnostic builds only (LWS_EXTRA_FLAGS="-DLWS_STAMPS=<kernel id>"; tools/stamps.py): every workgroup of the selected
 // kernel stores s_memtime stamps of its phases in a per-translation-unit buffer.  The shipped library compiles
 // LWS_STAMPK to nothing.  Kernel ids: 1 mid16, 2 mid8, 3 conv3d_last, 4 conv3d_first, 5 ref_dws, 6 ref_conv64,
-// 7 conv2d_nchw, 8 ref_first, 9 ref_last, 10 volume_warp, 11 volume_shift, 12 softargmin_upsample, 13..16 conv2d_pair (dres0, dres1, conv1+2, conv3+4), 17 ref_dws2, 18 conv3d_mid8s.
+// 7 conv2d_nchw, 8 ref_first, 9 ref_last, 10 volume_warp, 11 volume_shift, 12 softargmin_upsample, 13..16 conv2d_pair (dres0, dres1, conv1+2, conv3+4), 18 conv3d_mid8q.
 #ifdef LWS_STAMPS
 #define LWS_DEFINE_STAMPS(tu)                                                                                      \
     __device__ unsigned long long g_stamps_##tu[4096 * 8];                                                         \
@@ -93,7 +108,7 @@ struct Conv3dLayer {
 
 struct Stage3d {
     int c3 = 0;
-    int mid8_stream = 0;               // k_conv3d_mid8s (d-streaming) for the 8 -> 8 layers: 0 = never (default), 1 = always
+    int mid8_form = 0;                 // 8 -> 8 layers: 0 = k_conv3d_mid8 (16x16x4, parity rows), 1 = k_conv3d_mid8q (4x4x1_16B)
     std::vector<Conv3dLayer> layers;   // layers_3d + 2
 };
 
@@ -111,12 +126,14 @@ struct Conv2dLayer {
 // Refinement: BatchNorm(32) -> ReLU -> depthwise 3x3 (dil) -> pointwise 32->32
 struct RefDws {
     int dil = 1;
+    int order = 0;         // block -> tile order (option "ref_order", ref_tile in lws_conv2d.hip)
     float *bn_s = nullptr, *bn_t = nullptr;
     float *dw = nullptr;   // [tap][32]
     float *pw = nullptr;   // MFMA A fragments [q][mt][lane][4]
 };
 
 struct RefConv64 {
+    int order = 0;
     float *bn_s = nullptr, *bn_t = nullptr;   // [64]
     float *w = nullptr;                       // MFMA A fragments [tap][qq][mt][lane][4]
 };
@@ -146,8 +163,9 @@ struct lws_ctx {
         int fuse_shift = 1;        // stage-1 volume inside the first Conv3D launch
         int fuse_first = 1;        // refinement1_disp's 1 -> 32 convolution inside its first depthwise block
         int defer_upsample = 1;    // batches <= 2: consumers evaluate the stage-2/3 maps (no k_upsample_add launches)
-        int mid8_stream = 0;       // 8 -> 8 Conv3D layers in the d-streaming form (k_conv3d_mid8s; measured r02: no faster)
-        int fuse_dws = 0;          // consecutive depthwise-separable blocks of the refinement pairwise in one launch (measured slower, r02)
+        int mid8_form = 0;         // 8 -> 8 Conv3D layers: 0 = k_conv3d_mid8 (16x16x4), 1 = k_conv3d_mid8q (4x4x1_16B, no zero padding)
+        int side_streams = 1;      // 0: no handle-owned side streams, the whole forward on the caller's stream (lws_pool workers)
+        int ref_order = 0;         // block -> tile order of the phase-grid refinement kernels (0 = dispatch order, 1/2 = XCD-contiguous)
     } opt;
     unsigned prof_mask = 0;                  // kernel classes being timed in the current call
     unsigned prof_mask_cfg = 0;              // ... as configured by lws_profile_enable
@@ -161,6 +179,7 @@ struct lws_ctx {
     std::map<std::string, std::vector<int64_t>> shapes;
     std::map<std::string, std::vector<int64_t>> spec;      // accepted keys -> shapes (from cfg)
     float *params = nullptr;                                // one device slab for all packed params
+    bool owns_params = true;                                // false: a clone (lws_clone) sharing its source's slab
     size_t params_bytes = 0;
     lws::Stage3d stage[3];
     lws::Net2d net2d;
@@ -212,8 +231,6 @@ int launch_conv2d_pair(const Conv2dLayer &a, const Conv2dLayer &b, const float *
                        int H, int W, hipStream_t st, const float *in2 = nullptr, int n1 = 0);
 int launch_ref_first(const float *in, int cin, const float *w, float *out, int B, int H, int W, hipStream_t st);
 int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, int W, hipStream_t st);
-bool ref_dws_pair_can_fuse(const RefDws &a, const RefDws &b);
-int launch_ref_dws_pair(const RefDws &a, const RefDws &b, const float *in, float *out, int B, int H, int W, hipStream_t st);
 bool ref_first_dws_can_fuse(const RefDws &l, int cin);
 int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst, float *out, int B, int H, int W,
                          hipStream_t st, const float *plow = nullptr, int ph = 0, int pw = 0, float *pmat = nullptr);

@@ -326,11 +326,10 @@ static int conv2d_pair_launch(const Conv2dLayer &a, const Conv2dLayer &b, const 
         return LWS_ERR_STATE;
     }
     const size_t lds = (size_t)Cfg::LDS_FLOATS * sizeof(float);
-    static bool attr_done = false;
-    if (lds > 48 * 1024 && !attr_done) {
-        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv2d_pair<CIN, CM, COUT, SA, DA, DB, NW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+    static std::atomic<uint64_t> attr_done{0};
+    if (lds > 48 * 1024) {
+        const int rc_ = ensure_dyn_lds(attr_done, reinterpret_cast<const void *>(&k_conv2d_pair<CIN, CM, COUT, SA, DA, DB, NW>), (int)lds);
+        if (rc_) return rc_;
     }
     dim3 grid(cdiv(WA, 8), cdiv(HA, 8), N), block(Cfg::NT);
     hipLaunchKernelGGL((k_conv2d_pair<CIN, CM, COUT, SA, DA, DB, NW>), grid, block, lds, st, in, in2, n1, a.w_pair, a.bn_s,
@@ -614,17 +613,35 @@ struct RefTile {
     int b, Y0, X0;
 };
 
-__device__ __forceinline__ RefTile ref_tile(int dil, int nbx, int nby, int tile_rows = RT_Y)
+// order (launch-plan option "ref_order", speed only -- the tiles partition the image under every order):
+//   0  dispatch order: block id -> (phase fastest, bx, by, image).  Consecutive blocks, i.e. DIFFERENT XCDs, own the
+//      phases of one image block; a tile's halo neighbours (same phase, adjacent image block) sit d*d or nbx*d*d blocks
+//      away, in another XCD's L2 whenever d*d is not a multiple of 8.
+//   1  XCD-contiguous: each XCD walks one contiguous run of that same list (xcd_tile), so all phases of an image block
+//      and its neighbours stream through ONE L2.
+//   2  XCD-contiguous with the phase slowest inside an image: consecutive tiles of an XCD are halo neighbours.
+__device__ __forceinline__ RefTile ref_tile(int dil, int nbx, int nby, int tile_rows = RT_Y, int order = 0)
 {
-    int bid = blockIdx.x;
+    int bid = order == 0 ? (int)blockIdx.x : xcd_tile(blockIdx.x, gridDim.x);
     const int d2 = dil * dil;
-    const int phase = bid % d2;
-    bid /= d2;
-    const int bx = bid % nbx;
-    bid /= nbx;
-    const int by = bid % nby;
+    int phase, bx, by;
+    if (order == 2) {
+        bx = bid % nbx;
+        bid /= nbx;
+        by = bid % nby;
+        bid /= nby;
+        phase = bid % d2;
+        bid /= d2;
+    } else {
+        phase = bid % d2;
+        bid /= d2;
+        bx = bid % nbx;
+        bid /= nbx;
+        by = bid % nby;
+        bid /= nby;
+    }
     RefTile t;
-    t.b = bid / nby;
+    t.b = bid;
     t.Y0 = by * tile_rows * dil + phase / dil;
     t.X0 = bx * RT_X * dil + phase % dil;
     return t;
@@ -657,7 +674,8 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
                                                  const float *__restrict__ bn_t, const float *__restrict__ dw,   // [tap][32]
                                                  const float4 *__restrict__ pwpk,                              // [q][mt][lane]
                                                  float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt,
-                                                 const float *__restrict__ plow, int ph, int pw, float *__restrict__ pmat)
+                                                 const float *__restrict__ plow, int ph, int pw, float *__restrict__ pmat,
+                                                 int order)
 {
     // (FIRST only) plow != nullptr: the disparity map has not been materialised -- it is evaluated on demand as
     // upsample(plow [ph,pw]) + in (DeferredMap) and this workgroup writes its own tile pixels of it to pmat (the
@@ -665,7 +683,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
     __shared__ float4 sA[8 * DWS_SA];
     __shared__ float4 sB[8 * DWS_SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const RefTile t = ref_tile(dil, nbx, nby);
+    const RefTile t = ref_tile(dil, nbx, nby, RT_Y, order);
     LWS_STAMPK(5, 0);
 
     const int c4 = tid & 7;
@@ -826,297 +844,6 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
 }
 
 // =============================================================================================
-// TWO consecutive depthwise-separable blocks in one launch (k_ref_dws2): block A (dilation a) then block B (dilation b)
-// with M = min(a, b) dividing both -- the pairs of the refinement are (2,4), (4,8), (8,16) (refinement1,
-// submodules.py:298) and (8,4), (2,1) (refinement2, :316).  On the phase grid of modulus M both blocks are dense-ish
-// 3x3 problems with dilations DA = a/M and DB = b/M in {1, 2}; a workgroup owns RT_Y x RT_X phase pixels of B's output,
-// computes A on the (RT_Y + 2 DB) x (RT_X + 2 DB) region B's taps read (recomputing A's halo instead of a 16.8 MB
-// round trip through HBM/L2 per image and one more launch) and keeps it in LDS:
-//   1. stage A's input region (R0: 14 x 22 phase pixels for both pairings) with BN_A + ReLU, zeros outside the image;
-//   2. depthwise A on VALU over region R1 -> LDS in MFMA B-operand order;
-//   3. pointwise A on fp32 MFMA over R1 as a flat list of 16-pixel tiles; epilogue = BN_B + ReLU (zeros outside the
-//      image: B's padding is applied after its BatchNorm + ReLU, as in the unfused launch) -> LDS image of B's input,
-//      planar by 4-channel group (a lane's 4 accumulator registers are exactly one group), aliased onto the R0 image;
-//   4. depthwise B over the tile; 5. pointwise B on MFMA; store the raw result.
-// Every value is produced by the same fmaf / MFMA chains as two k_ref_dws launches: bit-identical.
-// LDS 70.7 KB (2 workgroups per CU); reads 2.4 lines per output pixel instead of 2 x 1.56 + the intermediate's write + read.
-// =============================================================================================
-// Depthwise 3x3 (dilation D) for a VERTICAL strip of S pixels spaced D rows apart, one 4-channel group: the 3 x (S + 2)
-// taps the strip touches are read once (instead of 9 per pixel) and every pixel still accumulates its own taps in (kh, kw)
-// ascending order -- the same fmaf chain as one pixel at a time.  src points at the strip's first pixel's (kh, kw) = (0, 0)
-// tap; wv (this channel group's [tap][4] weights) is wave-uniform -- the lanes of a wave sweep pixels of ONE channel group --
-// so it sits in SGPRs.
-template <int D, int S>
-__device__ __forceinline__ void dw_vstrip(const float4 *src, int row_stride, const float (&wv)[9][4], float4 (&acc)[S])
-{
-    // all 3 (S + 2) taps are requested before the first fmaf: one LDS round trip per strip instead of one per tap (left to
-    // itself hipcc keeps two ds_read_b128 in flight and waits on each); the 36 scalar weights were loaded by the caller
-    float4 tap[S + 2][3];
-#pragma unroll
-    for (int c = 0; c < S + 2; ++c)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) tap[c][kw] = src[(c * D) * row_stride + kw * D];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s_ = 0; s_ < S; ++s_) acc[s_] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int c = 0; c < S + 2; ++c)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const float4 a = tap[c][kw];
-#pragma unroll
-            for (int s_ = 0; s_ < S; ++s_) {
-                const int kh = c - s_;
-                if (kh >= 0 && kh <= 2) {
-                    acc[s_].x = fmaf(a.x, wv[kh * 3 + kw][0], acc[s_].x);
-                    acc[s_].y = fmaf(a.y, wv[kh * 3 + kw][1], acc[s_].y);
-                    acc[s_].z = fmaf(a.z, wv[kh * 3 + kw][2], acc[s_].z);
-                    acc[s_].w = fmaf(a.w, wv[kh * 3 + kw][3], acc[s_].w);
-                }
-            }
-        }
-}
-
-template <int DA, int DB>
-struct Dws2Cfg {
-    static constexpr int R1Y = RT_Y + 2 * DB, R1X = RT_X + 2 * DB, N1 = R1Y * R1X;   // block A's output region
-    static constexpr int R0Y = R1Y + 2 * DA, R0X = R1X + 2 * DA, N0 = R0Y * R0X;     // block A's input region
-    static constexpr int NT1 = (N1 + 15) / 16, TPW = (NT1 + 3) / 4;                 // pointwise-A pixel tiles (per wave)
-    // R0 / R1 images: planar by 4-channel group, plane stride in float4 with (4 * stride) % 64 an odd multiple of 8 dwords
-    static constexpr int pad(int n) { return n + ((2 - n % 4) + 4) % 4; }
-    static constexpr int S0 = pad(N0);
-    // depthwise results: planar by CHANNEL, [32][SP] floats, SP % 32 == 16: the MFMA B operand of lane (n, g) is one
-    // ds_read_b32 per (q, j) at plane 16 q + 4 j + g, pixel 16 tile + n -- lanes (n, g in {0,1}) hit 32 different banks
-    static constexpr int SP = ((NT1 * 16 + 15) / 32) * 32 + 16;
-    static constexpr int SITER = (N0 * 8 + 255) / 256;
-    // vertical depthwise strips: SVA rows spaced DA in R1 (lanes = strips x R1X columns), SVB = 2 rows spaced DB in the tile
-    static constexpr int SVA = DA == 1 ? 4 : 5, NVA = R1Y / SVA, LANES_A = NVA * R1X;
-    static constexpr int SVB = 2, NVB = RT_Y / SVB;
-    static_assert(R1Y % (SVA * DA) == 0 && RT_Y % (SVB * DB) == 0 && LANES_A <= 64 && NVB * RT_X == 64, "strip geometry");
-    static constexpr int LDS_BYTES = 8 * S0 * 16 + 32 * SP * 4;
-    static_assert(S0 >= N1 && SP >= NT1 * 16 && SP >= RT_Y * RT_X, "aliased images must fit");
-};
-
-template <int DA, int DB>
-__global__ __launch_bounds__(256) void k_ref_dws2(const float *__restrict__ in,                    // [B,H,W,32]
-                                                  const float *__restrict__ bnA_s, const float *__restrict__ bnA_t,
-                                                  const float *__restrict__ dwA, const float4 *__restrict__ pwA,
-                                                  const float *__restrict__ bnB_s, const float *__restrict__ bnB_t,
-                                                  const float *__restrict__ dwB, const float4 *__restrict__ pwB,
-                                                  float *__restrict__ out, int H, int W, int M, int nbx, int nby, int wt)
-{
-    using Cfg = Dws2Cfg<DA, DB>;
-    constexpr int R1X = Cfg::R1X, N1 = Cfg::N1, R0X = Cfg::R0X, N0 = Cfg::N0, S0 = Cfg::S0, SP = Cfg::SP;
-    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-    float4 *sA = lds4;                                          // [8][S0]: R0 image (BN_A+ReLU'd input), later the R1 image
-    float *sP = reinterpret_cast<float *>(lds4 + 8 * S0);       // [32][SP]: depthwise results (A over R1, later B over the tile)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR: the depthwise weight addresses become scalar loads
-    const RefTile t = ref_tile(M, nbx, nby);
-    const int c4 = tid & 7;
-    const int n = lane & 15, g = lane >> 4;
-    LWS_STAMPK(17, 0);
-
-    // depthwise weights of this wave's two channel groups (wave-uniform addresses -> s_load into SGPRs), requested first so
-    // that the scalar-cache round trip hides behind the staging loads
-    float wdw[2][9][4];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-        for (int t9 = 0; t9 < 9; ++t9)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) wdw[pass][t9][e] = dwA[t9 * 32 + 4 * (2 * wave + pass) + e];
-    // per-lane parameters of the two pointwise steps, loaded behind the staging loads
-    float4 awA[2][2], awB[2][2], es[2], et[2];
-
-    // ---- 1. stage R0: item = (pixel hp, 4-channel group c4); all loads in flight before the first LDS write ----
-    {
-        const float4 s4 = *reinterpret_cast<const float4 *>(bnA_s + c4 * 4);
-        const float4 t4 = *reinterpret_cast<const float4 *>(bnA_t + c4 * 4);
-        const float *inb = in + (int64_t)t.b * H * W * 32;
-        float4 c[Cfg::SITER];
-        bool okv[Cfg::SITER];
-#pragma unroll
-        for (int i = 0; i < Cfg::SITER; ++i) {
-            const int hp = (tid >> 3) + 32 * i;
-            const int hy = hp / R0X, hx = hp - hy * R0X;
-            const int gy = t.Y0 + (hy - DA - DB) * M, gx = t.X0 + (hx - DA - DB) * M;
-            okv[i] = hp < N0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const int off = okv[i] ? (gy * W + gx) * 32 + c4 * 4 : 0;      // one image < 2^31 floats
-            c[i] = *reinterpret_cast<const float4 *>(inb + off);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                awA[q][mt] = pwA[(q * 2 + mt) * 64 + lane];
-                awB[q][mt] = pwB[(q * 2 + mt) * 64 + lane];
-            }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            es[mt] = *reinterpret_cast<const float4 *>(bnB_s + 16 * mt + 4 * g);
-            et[mt] = *reinterpret_cast<const float4 *>(bnB_t + 16 * mt + 4 * g);
-        }
-#pragma unroll
-        for (int i = 0; i < Cfg::SITER; ++i) {
-            const int hp = (tid >> 3) + 32 * i;
-            float4 v = make_float4(bn_relu2(c[i].x, s4.x, t4.x), bn_relu2(c[i].y, s4.y, t4.y), bn_relu2(c[i].z, s4.z, t4.z),
-                                   bn_relu2(c[i].w, s4.w, t4.w));
-            if (!okv[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hp < N0) sA[c4 * S0 + hp] = v;
-        }
-    }
-    __syncthreads();
-    LWS_STAMPK(17, 1);
-
-    // ---- 2. depthwise A over R1.  Wave w owns channel groups 2 w and 2 w + 1 (weights in SGPRs); its lanes are
-    //         (strip, column): a vertical strip of SVA rows spaced DA, so consecutive lanes read and write consecutive
-    //         LDS addresses (conflict-free) and the strip's taps are read once ----
-    {
-        const int st_ = lane / R1X, x = lane - st_ * R1X;
-        const int ry0 = (st_ % DA) + DA * Cfg::SVA * (st_ / DA);            // first row of the strip
-        if (lane < Cfg::LANES_A) {
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int cg = 2 * wave + pass;                             // wave-uniform channel group
-                float4 acc[Cfg::SVA];
-                dw_vstrip<DA, Cfg::SVA>(sA + cg * S0 + ry0 * R0X + x, R0X, wdw[pass], acc);
-#pragma unroll
-                for (int s_ = 0; s_ < Cfg::SVA; ++s_) {
-                    float *dst = sP + (4 * cg) * SP + (ry0 + DA * s_) * R1X + x;
-                    dst[0] = acc[s_].x;
-                    dst[SP] = acc[s_].y;
-                    dst[2 * SP] = acc[s_].z;
-                    dst[3 * SP] = acc[s_].w;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    LWS_STAMPK(17, 2);
-    // block B's depthwise weights take over the SGPRs; the round trip hides behind the pointwise step
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-        for (int t9 = 0; t9 < 9; ++t9)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) wdw[pass][t9][e] = dwB[t9 * 32 + 4 * (2 * wave + pass) + e];
-
-    // ---- 3. pointwise A on MFMA over the flat 16-pixel tiles of R1 (two tiles = four accumulator chains at a time);
-    //         epilogue BN_B + ReLU (zeros outside the image) -> sA = B's input image ----
-    {
-#pragma unroll
-        for (int k = 0; k < Cfg::TPW; k += 2) {
-            const int tile0 = wave * Cfg::TPW + k;
-            if (tile0 < Cfg::NT1) {                                  // wave-uniform
-                const bool two = (k + 1 < Cfg::TPW) && (tile0 + 1 < Cfg::NT1);
-                int p1[2];
-                float bv[2][2][4];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    p1[u] = (tile0 + (two ? u : 0)) * 16 + n;
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) bv[u][q][j] = sP[(16 * q + 4 * j + g) * SP + p1[u]];
-                }
-                floatx4 acc[2][2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[u][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-#pragma unroll
-                            for (int mt = 0; mt < 2; ++mt)
-                                if (u == 0 || two)
-                                    acc[u][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(awA[q][mt], j), bv[u][q][j], acc[u][mt], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (u == 1 && !two) continue;
-                    const int ry = p1[u] / R1X, rx = p1[u] - ry * R1X;
-                    const int gy = t.Y0 + (ry - DB) * M, gx = t.X0 + (rx - DB) * M;
-                    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                    if (p1[u] < N1) {
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            float4 v = make_float4(bn_relu2(acc[u][mt][0], es[mt].x, et[mt].x), bn_relu2(acc[u][mt][1], es[mt].y, et[mt].y),
-                                                   bn_relu2(acc[u][mt][2], es[mt].z, et[mt].z), bn_relu2(acc[u][mt][3], es[mt].w, et[mt].w));
-                            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                            sA[(4 * mt + g) * S0 + p1[u]] = v;       // channels 16 mt + 4 g .. + 3 = group 4 mt + g
-                        }
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    LWS_STAMPK(17, 3);
-
-    // ---- 4. depthwise B over the tile: lanes = (strip of 2 rows spaced DB, column), two channel groups per wave ----
-    {
-        const int st_ = lane >> 4, x = lane & 15;
-        const int ry0 = (st_ % DB) + DB * Cfg::SVB * (st_ / DB);
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int cg = 2 * wave + pass;
-            float4 acc[Cfg::SVB];
-            dw_vstrip<DB, Cfg::SVB>(sA + cg * S0 + ry0 * R1X + x, R1X, wdw[pass], acc);
-#pragma unroll
-            for (int s_ = 0; s_ < Cfg::SVB; ++s_) {
-                float *dst = sP + (4 * cg) * SP + (ry0 + DB * s_) * RT_X + x;
-                dst[0] = acc[s_].x;
-                dst[SP] = acc[s_].y;
-                dst[2 * SP] = acc[s_].z;
-                dst[3 * SP] = acc[s_].w;
-            }
-        }
-    }
-    __syncthreads();
-    LWS_STAMPK(17, 4);
-
-    // ---- 5. pointwise B: wave handles tile rows 2*wave, 2*wave+1 x both output-channel tiles; store raw ----
-    floatx4 acc[2][2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    float bv[2][2][4];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bv[r][q][j] = sP[(16 * q + 4 * j + g) * SP + (2 * wave + r) * RT_X + n];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(awB[q][mt], j), bv[r][q][j], acc[r][mt], 0, 0, 0);
-    float *outb = out + (int64_t)t.b * H * W * 32;
-    const int gx = t.X0 + n * M;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int gy = t.Y0 + (2 * wave + r) * M;
-        if (gy < H && gx < W) {
-            float *o = outb + (gy * W + gx) * 32;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                store_act4(o + mt * 16 + 4 * g, make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]), wt);
-        }
-    }
-    LWS_STAMPK(17, 5);
-}
-
-// =============================================================================================
 // refinement2[0] (submodules.py:304-309): BatchNorm(64) -> ReLU -> Conv 3x3 dilation 8, 64 -> 32, on the
 // concatenation [refined_left, refined_disp] (models.py:160) -- the concat is never materialised: the two
 // channels-last maps are staged side by side.  fp32-MFMA implicit GEMM, K = 9 taps x 64 channels = 144 MFMAs per
@@ -1126,13 +853,14 @@ template <int TY, int NW>   // tile rows, waves per workgroup (TY/NW rows each)
 __global__ __launch_bounds__(64 * NW) void k_ref_conv64(const float *__restrict__ inL, const float *__restrict__ inD,
                                                     const float *__restrict__ bn_s, const float *__restrict__ bn_t,   // [64]
                                                     const float4 *__restrict__ wpk,   // [tap][qq][mt][lane]
-                                                    float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt)
+                                                    float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt,
+                                                    int order)
 {
     constexpr int HY = TY + 2, NPX = HY * RH_X, RW = TY / NW, NT = 64 * NW;
     static_assert(TY % NW == 0 && RW >= 1 && RW <= 4, "rows must split evenly over the waves");
     __shared__ __attribute__((aligned(16))) float sA[2 * NPX * RVS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const RefTile t = ref_tile(dil, nbx, nby, TY);
+    const RefTile t = ref_tile(dil, nbx, nby, TY, order);
     const int n = lane & 15, g = lane >> 4;
     LWS_STAMPK(6, 0);
 
@@ -1327,51 +1055,9 @@ int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, i
     dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
     hipLaunchKernelGGL(k_ref_dws<false>, grid, block, 0, st, in, (const float *)nullptr, l.bn_s, l.bn_t, l.dw,
                        reinterpret_cast<const float4 *>(l.pw), out, H, W, l.dil, nbx, nby,
-                       use_wt_stores((size_t)B * H * W * 128), (const float *)nullptr, 0, 0, (float *)nullptr);
+                       use_wt_stores((size_t)B * H * W * 128), (const float *)nullptr, 0, 0, (float *)nullptr, l.order);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
-}
-
-// blocks a then b in one launch (k_ref_dws2); the dilation pairs of the refinement: (2,4) (4,8) (8,16) (8,4) (2,1)
-bool ref_dws_pair_can_fuse(const RefDws &a, const RefDws &b)
-{
-    const int M = a.dil < b.dil ? a.dil : b.dil;
-    if (M < 1 || a.dil % M || b.dil % M) return false;
-    const int da = a.dil / M, db = b.dil / M;
-    return (da == 1 && db == 2) || (da == 2 && db == 1);
-}
-
-template <int DA, int DB>
-static int dws2_launch(const RefDws &a, const RefDws &b, const float *in, float *out, int B, int H, int W, int M, hipStream_t st)
-{
-    using Cfg = Dws2Cfg<DA, DB>;
-    static unsigned attr_devs = 0;                     // one bit per device: the attribute is per (function, device)
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    const bool attr_set = (attr_devs >> (dev_ & 31)) & 1u;
-    if (!attr_set) {
-        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ref_dws2<DA, DB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr_devs |= 1u << (dev_ & 31);
-    }
-    const int nbx = cdiv(W, RT_X * M), nby = cdiv(H, RT_Y * M);
-    dim3 grid(nbx * nby * M * M * B), block(256);
-    hipLaunchKernelGGL((k_ref_dws2<DA, DB>), grid, block, Cfg::LDS_BYTES, st, in, a.bn_s, a.bn_t, a.dw,
-                       reinterpret_cast<const float4 *>(a.pw), b.bn_s, b.bn_t, b.dw, reinterpret_cast<const float4 *>(b.pw), out,
-                       H, W, M, nbx, nby, use_wt_stores((size_t)B * H * W * 128));
-    LWS_LAUNCH_CHECK();
-    return LWS_OK;
-}
-
-int launch_ref_dws_pair(const RefDws &a, const RefDws &b, const float *in, float *out, int B, int H, int W, hipStream_t st)
-{
-    if (!ref_dws_pair_can_fuse(a, b)) {
-        set_error("ref_dws_pair: dilations %d, %d cannot be fused", a.dil, b.dil);
-        return LWS_ERR_INVALID;
-    }
-    const int M = a.dil < b.dil ? a.dil : b.dil;
-    if (a.dil == M) return dws2_launch<1, 2>(a, b, in, out, B, H, W, M, st);
-    return dws2_launch<2, 1>(a, b, in, out, B, H, W, M, st);
 }
 
 // 1 -> 32 first convolution + the first depthwise-separable block in one launch (disparity branch of refinement1)
@@ -1388,7 +1074,7 @@ int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst,
     dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
     hipLaunchKernelGGL(k_ref_dws<true>, grid, block, 0, st, img, wfirst, l.bn_s, l.bn_t, l.dw,
                        reinterpret_cast<const float4 *>(l.pw), out, H, W, l.dil, nbx, nby,
-                       use_wt_stores((size_t)B * H * W * 128), plow, ph, pw, pmat);
+                       use_wt_stores((size_t)B * H * W * 128), plow, ph, pw, pmat, l.order);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -1403,7 +1089,7 @@ int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, fl
         dim3 grid(nbx * nby * dil * dil * B), block(64 * NWv);                                                      \
         hipLaunchKernelGGL((k_ref_conv64<TYv, NWv>), grid, block, 0, st, inL, inD, l.bn_s, l.bn_t,                   \
                            reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby,                         \
-                           use_wt_stores((size_t)B * H * W * 128));                                                 \
+                           use_wt_stores((size_t)B * H * W * 128), l.order);                                        \
     }
     // 8-row tiles, 4 waves x 2 rows (46 KB LDS: 3 workgroups per CU): 50.5 / 349 us at B = 1 / 8 (r01, 256x512; the floor
     // is 31 / 246 us of fp32 MFMA issue).  Measured and dropped: 4-row tiles x 4 waves 54.3 / 390 us, 4-row x 2 waves

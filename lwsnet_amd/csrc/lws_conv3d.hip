@@ -13,6 +13,7 @@
 //   k_conv3d_first8 / k_conv3d_first16   cin = 1 -> C3   fp32 MFMA (K = 27 taps)
 //   k_conv3d_mid16  C3 % 16 == 0     fp32 MFMA implicit GEMM, M = cout tile, N = 16 voxels along x
 //   k_conv3d_mid8   C3 == 8          fp32 MFMA, M = (x parity, cout) so that all 16 MFMA rows work
+//   k_conv3d_mid8q  C3 == 8          v_mfma_f32_4x4x1_16B_f32 with A-block broadcast: 4 couts x 64 voxels, no padding
 //   k_conv3d_last   C3 -> 1 + skip   VALU (K = 27*C3)
 #include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
@@ -74,15 +75,6 @@ struct Mid16Cfg {
     static_assert(ROWS % WR == 0 && MT % WM == 0, "tile must split evenly over the waves");
     static_assert(RW * MTW >= 2 || NW == 8, "need >= 2 independent accumulator chains per SIMD");
 };
-
-// XCD-aware block -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD a
-// contiguous run of tiles; neighbouring tiles then find each other's halo voxels in the same L2.
-// Speed only: any placement is correct.
-__device__ __forceinline__ int xcd_tile(int b, int nb)
-{
-    const int q = nb >> 3, r = nb & 7, x = b & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-}
 
 template <int C3, int TD, int TY, int WR, int WM>
 __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__restrict__ in,     // [B,D,h,w,C3]
@@ -450,191 +442,143 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
 }
 
 // =============================================================================================
-// Middle layers, C3 == 8, d-streaming form (k_conv3d_mid8s): the same MFMA scheme and the same chains as k_conv3d_mid8
-// (rows = (x parity, cout), 72 resident A fragments, planar LDS image), but a workgroup owns a TY x 32 column of the
-// volume over ALL d and walks it two planes at a time.  The LDS image is a ring of 6 d-planes: planes d-1 .. d+2 feed
-// the two planes being computed (two accumulator chains per wave that share every A fragment), while planes d+3, d+4
-// are in flight from L2 into registers under the MFMAs and are written to the two free slots afterwards -- one barrier
-// per pair of planes.  Against the 3-deep tile this removes the d halo (5/3 of the reads) and the "everyone stages,
-// then everyone computes" phase structure (profiles/r01: SQ_WAIT_INST_ANY 65 % at stage 3): only the first four planes
-// are loaded with nothing to hide behind.  39.4 KB of LDS: 4 workgroups per CU.
+// Middle layers, C3 == 8, on v_mfma_f32_4x4x1_16B_f32 (k_conv3d_mid8q, option "mid8_form" = 1).
+//
+// The 16x16x4 form above pays 25 % of every instruction for structural zeros (two output positions share a 16-row
+// tile, their windows overlap in 2 of 3 taps).  The multi-block MFMA has no such padding: one instruction is 16
+// independent 4x4 outer products with K = 1,  D_b[i][j] += A_b[i] * B_b[j]  (b = block = lane / 4), and with the A-block
+// broadcast (CBSZ = 4, ABID = k) all 16 blocks take block k's A.  So
+//     lane l = voxel l of a 64-voxel group (2 rows x 32 along x)  ->  B operand = ONE activation value per lane,
+//     A = W[4 cg .. 4 cg + 3][cin][tap] held by lanes 4k .. 4k+3 of a register, k = 2 cin + cg,
+//     D register i of lane l = output channel 4 cg + i of voxel l:
+// one instruction = 4 output channels x 64 voxels x 1 (tap, cin) term, every FLOP useful, and ONE register holds all
+// 16 (cin, cg) weight blocks of a tap -- 27 A registers for the whole layer instead of 72.  The chain per output is the
+// contract's: taps (kd,kh,kw) outer, cin ascending, one fma each (K = 1).
+// Wave = one 64-voxel group, two accumulators (cout 0-3, 4-7); workgroup = TD x TY x 32 voxels = TD*TY/2 waves; the
+// halo tile sits in LDS channels-last as two half-planes [cin half][voxel] of float4 (one ds_read_b128 at lane base +
+// immediate feeds 8 MFMAs; consecutive lanes read consecutive 16-byte slots: conflict-free).  Latency is hidden by the
+// 5-6 co-resident waves per SIMD, not by software pipelining inside a wave (64 VGPRs).
 // =============================================================================================
-template <int TY, int WP>
-struct Mid8sCfg {
-    static constexpr int HY = TY + 2, HX = 34;
-    static constexpr int NV = HY * HX;                              // voxels of one d-plane of the halo column
-    static constexpr int PS = (NV % 2 == 0) ? NV + 1 : NV;          // odd channel-plane stride (floats)
-    static constexpr int SLOT = 8 * PS;                             // one d-plane: 8 channel planes
-    static constexpr int NSLOT = 6;
-    static constexpr int ITEMS = NV * 2;                            // (voxel, half) items of one d-plane
-    static constexpr int NT = 64 * TY * WP;
-    static constexpr int SITER = (ITEMS + NT - 1) / NT;
-    static constexpr int LDS_BYTES = NSLOT * SLOT * 4;
+template <int TD, int TY>
+struct Mid8qCfg {
+    static_assert(TY % 2 == 0, "a wave owns two rows of 32 voxels");
+    static constexpr int NW = TD * TY / 2, NT = 64 * NW;
+    static constexpr int HD = TD + 2, HY = TY + 2, HX = 34;
+    static constexpr int NVOX = HD * HY * HX;
+    // half-plane stride in float4, == 4 (mod 8): the staging's ds_write_b128 of neighbouring lanes (alternating halves)
+    // then fall on different banks
+    static constexpr int NP = NVOX + ((4 - NVOX % 8) + 8) % 8;
+    static constexpr int ITEMS = 2 * NVOX, SITER = (ITEMS + NT - 1) / NT;
+    static constexpr int LDS_BYTES = 2 * NP * 16;
 };
 
-template <int TY, int WP>
-__global__ __launch_bounds__(64 * TY * WP) void k_conv3d_mid8s(const float *__restrict__ in,      // [B,D,h,w,8]
-                                                         const float *__restrict__ wpk,     // [18][64][4] A fragments
-                                                         const float *__restrict__ bn_s,    // next layer BN [8]
-                                                         const float *__restrict__ bn_t,
-                                                         float *__restrict__ out, int D, int h, int w,
-                                                         int tiles_x, int wt)
+// one (tap, cin) term for both output-channel groups; ABID must be a literal
+#define LWS_Q2(CIN, BV)                                                                    \
+    lo = __builtin_amdgcn_mfma_f32_4x4x1f32(aw, (BV), lo, 4, 2 * (CIN), 0);                \
+    hi = __builtin_amdgcn_mfma_f32_4x4x1f32(aw, (BV), hi, 4, 2 * (CIN) + 1, 0);
+
+template <int TD, int TY>
+__global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const float *__restrict__ in,      // [B,D,h,w,8]
+                                                                        const float *__restrict__ wpk,     // [7][64][4]
+                                                                        const float *__restrict__ bn_s,    // next layer BN [8]
+                                                                        const float *__restrict__ bn_t,
+                                                                        float *__restrict__ out, int D, int h, int w,
+                                                                        int tiles_x, int tiles_y, int wt)
 {
-    using Cfg = Mid8sCfg<TY, WP>;
-    constexpr int HY = Cfg::HY, HX = Cfg::HX, PS = Cfg::PS, SLOT = Cfg::SLOT, NSLOT = Cfg::NSLOT, SITER = Cfg::SITER;
-    constexpr int NT = Cfg::NT;
+    using Cfg = Mid8qCfg<TD, TY>;
+    constexpr int HY = Cfg::HY, HX = Cfg::HX, NP = Cfg::NP, NT = Cfg::NT, SITER = Cfg::SITER;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4 *lds4 = reinterpret_cast<float4 *>(lds);
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 15, g = lane >> 4;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x;
+    tile /= tiles_x;
+    const int ty = tile % tiles_y;
+    const int td = tile / tiles_y;
     const int b = blockIdx.y;
-    const int x0 = tx * 32, y0 = ty * TY;
+    const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * 8;
     LWS_STAMPK(18, 0);
 
-    const int xpar = g >> 1, cb = 4 * (g & 1);
-    const float4 es8 = *reinterpret_cast<const float4 *>(bn_s + cb);
-    const float4 et8 = *reinterpret_cast<const float4 *>(bn_t + cb);
-    float wa[72];
+    // ---- stage: item = (voxel, channel half) = 16 B; all global loads of a thread are in flight before the first
+    //      LDS write; out-of-volume voxels become literal zeros (the convolution's padding)
+    float4 c[SITER];
+    bool okv[SITER];
 #pragma unroll
-    for (int s4 = 0; s4 < 18; ++s4) {
+    for (int i = 0; i < SITER; ++i) {
+        const int it = tid + i * NT;
+        const int half = it & 1, v = it >> 1;
+        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        okv[i] = it < Cfg::ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        c[i] = *reinterpret_cast<const float4 *>(inb + (okv[i] ? (((int64_t)gd * h + gy) * w + gx) * 8 + half * 4 : 0));
+    }
+    // the 27 A registers of this lane ([tap / 4][lane][tap % 4]) and the next layer's BatchNorm (wave-uniform)
+    float wa[28];
+#pragma unroll
+    for (int s4 = 0; s4 < 7; ++s4) {
         const float4 v = reinterpret_cast<const float4 *>(wpk)[s4 * 64 + lane];
         wa[4 * s4 + 0] = v.x;
         wa[4 * s4 + 1] = v.y;
         wa[4 * s4 + 2] = v.z;
         wa[4 * s4 + 3] = v.w;
     }
-
-    // staging of one d-plane: item = (voxel v of the (TY+2) x 34 halo plane, channel half); per-thread item geometry is
-    // the same for every plane, so it is computed once
-    int soff[SITER], sdst[SITER];
-    bool sok[SITER];
+    const float4 s_lo = *reinterpret_cast<const float4 *>(bn_s), s_hi = *reinterpret_cast<const float4 *>(bn_s + 4);
+    const float4 t_lo = *reinterpret_cast<const float4 *>(bn_t), t_hi = *reinterpret_cast<const float4 *>(bn_t + 4);
 #pragma unroll
     for (int i = 0; i < SITER; ++i) {
         const int it = tid + i * NT;
-        const int half = it & 1, v = it >> 1;
-        const int hx = v % HX, hy = v / HX;
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        sok[i] = it < Cfg::ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        soff[i] = sok[i] ? (gy * w + gx) * 8 + half * 4 : 0;          // offset inside one d-plane (h*w*8 floats < 2^31)
-        sdst[i] = it < Cfg::ITEMS ? (half * 4) * PS + v : -1;
-    }
-    const int64_t dplane = (int64_t)h * w * 8;
-    auto load_plane = [&](int d, float4 (&c)[SITER]) {                   // d may be outside [0, D): zeros then
-        const bool dok = d >= 0 && d < D;
-        const float *src = inb + (dok ? (int64_t)d * dplane : 0);
-#pragma unroll
-        for (int i = 0; i < SITER; ++i) c[i] = *reinterpret_cast<const float4 *>(src + soff[i]);
-        if (!dok) {
-#pragma unroll
-            for (int i = 0; i < SITER; ++i) c[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto write_plane = [&](int d, const float4 (&c)[SITER]) {
-        float *base = lds + ((d + NSLOT) % NSLOT) * SLOT;                 // plane d lives in slot (d mod 6), d >= -1
-#pragma unroll
-        for (int i = 0; i < SITER; ++i) {
-            if (sdst[i] >= 0) {
-                const float4 v4 = sok[i] ? c[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                float *dst = base + sdst[i];
-                dst[0] = v4.x;
-                dst[PS] = v4.y;
-                dst[2 * PS] = v4.z;
-                dst[3 * PS] = v4.w;
-            }
-        }
-    };
-
-    // ---- prologue: planes -1 (zeros), 0, 1, 2 ----
-    float4 ca[SITER], cc[SITER];
-    {
-        float4 c0[SITER], c1[SITER];
-        load_plane(0, c0);
-        load_plane(1, c1);
-        load_plane(2, ca);
-#pragma unroll
-        for (int i = 0; i < SITER; ++i) cc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        write_plane(-1, cc);
-        write_plane(0, c0);
-        write_plane(1, c1);
-        write_plane(2, ca);
+        if (it < Cfg::ITEMS) lds4[(it & 1) * NP + (it >> 1)] = okv[i] ? c[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     LWS_STAMPK(18, 1);
 
-    const int wrow = wave % TY, wpl = wave / TY;             // WP == 2: waves [0, TY) compute plane d, waves [TY, 2 TY) plane d + 1
-    const int rbase = g * PS + wrow * HX + 2 * n;            // this wave's output row of the column; halo row = wrow + kh
-    float *outb = out + (int64_t)b * D * h * w * 8;
-    const int gx = x0 + 2 * n + xpar, gy = y0 + wrow;
-
-#pragma unroll 1
-    for (int d = 0; d < D; d += 2) {
-        // next two planes: global -> registers, in flight under the MFMAs below
-        load_plane(d + 3, ca);
-        load_plane(d + 4, cc);
-        const bool two = d + 1 < D;                         // wave-uniform: the last pass of an odd D computes one plane
-        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        if (WP == 1) {
+    // ---- this wave's group: d-plane pd, rows 2 pr and 2 pr + 1, 32 voxels each
+    const int pd = wave / (TY / 2), pr = wave % (TY / 2);
+    const int ly = 2 * pr + (lane >> 5), lx = lane & 31;
+    const float4 *bp = lds4 + (pd * HY + ly) * HX + lx;
+    floatx4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kd = 0; kd < 3; ++kd) {
-                const float *p0 = lds + ((d - 1 + kd + NSLOT) % NSLOT) * SLOT + rbase;     // plane d - 1 + kd   (output plane d)
-                const float *p1 = lds + ((d + kd + NSLOT) % NSLOT) * SLOT + rbase;         // plane d + kd       (output plane d + 1)
+    for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const int step = ((kd * 3 + kh) * 4 + t) * 2 + half;
-                            const int off = half * 4 * PS + kh * HX + t;
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], p0[off], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], p1[off], acc1, 0, 0, 0);
-                        }
+            for (int kw = 0; kw < 3; ++kw) {
+                const int off = (kd * HY + kh) * HX + kw;
+                const float4 b0 = bp[off], b1 = bp[NP + off];
+                const float aw = wa[(kd * 3 + kh) * 3 + kw];
+                LWS_Q2(0, b0.x)
+                LWS_Q2(1, b0.y)
+                LWS_Q2(2, b0.z)
+                LWS_Q2(3, b0.w)
+                LWS_Q2(4, b1.x)
+                LWS_Q2(5, b1.y)
+                LWS_Q2(6, b1.z)
+                LWS_Q2(7, b1.w)
             }
-        } else if (wpl == 0 || two) {
-            // one plane per wave: two waves per SIMD (one of each group) cover each other's LDS and MFMA latencies
-#pragma unroll
-            for (int kd = 0; kd < 3; ++kd) {
-                const float *p0 = lds + ((d + wpl - 1 + kd + NSLOT) % NSLOT) * SLOT + rbase;
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const int step = ((kd * 3 + kh) * 4 + t) * 2 + half;
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], p0[half * 4 * PS + kh * HX + t], acc0, 0, 0, 0);
-                        }
-            }
-        }
-        // epilogue: next layer's BatchNorm + ReLU, 16-byte stores
-        if (gy < h && gx < w) {
-            float4 v;
-            if (WP == 1 || wpl == 0 || two) {
-                const int dd = d + (WP == 1 ? 0 : wpl);
-                v.x = bn_relu(acc0[0], es8.x, et8.x);
-                v.y = bn_relu(acc0[1], es8.y, et8.y);
-                v.z = bn_relu(acc0[2], es8.z, et8.z);
-                v.w = bn_relu(acc0[3], es8.w, et8.w);
-                store_act4(outb + (((int64_t)dd * h + gy) * w + gx) * 8 + cb, v, wt);
-            }
-            if (WP == 1 && two) {
-                v.x = bn_relu(acc1[0], es8.x, et8.x);
-                v.y = bn_relu(acc1[1], es8.y, et8.y);
-                v.z = bn_relu(acc1[2], es8.z, et8.z);
-                v.w = bn_relu(acc1[3], es8.w, et8.w);
-                store_act4(outb + (((int64_t)(d + 1) * h + gy) * w + gx) * 8 + cb, v, wt);
-            }
-        }
-        // planes d + 3, d + 4 take the slots of d - 3, d - 2, last read in the previous pass (its closing barrier is behind
-        // every wave); the next pass reads d + 1 .. d + 4
-        write_plane(d + 3, ca);
-        write_plane(d + 4, cc);
-        __syncthreads();
-    }
     LWS_STAMPK(18, 2);
+
+    // ---- epilogue: register i of lo / hi = output channel i / 4 + i of this lane's voxel; next layer's BN + ReLU;
+    //      32 contiguous bytes per lane, consecutive lanes consecutive voxels
+    const int gd = d0 + pd, gy = y0 + ly, gx = x0 + lx;
+    if (gd < D && gy < h && gx < w) {
+        float *o = out + (int64_t)b * D * h * w * 8 + (((int64_t)gd * h + gy) * w + gx) * 8;
+        float4 v;
+        v.x = bn_relu(lo[0], s_lo.x, t_lo.x);
+        v.y = bn_relu(lo[1], s_lo.y, t_lo.y);
+        v.z = bn_relu(lo[2], s_lo.z, t_lo.z);
+        v.w = bn_relu(lo[3], s_lo.w, t_lo.w);
+        store_act4(o, v, wt);
+        v.x = bn_relu(hi[0], s_hi.x, t_hi.x);
+        v.y = bn_relu(hi[1], s_hi.y, t_hi.y);
+        v.z = bn_relu(hi[2], s_hi.z, t_hi.z);
+        v.w = bn_relu(hi[3], s_hi.w, t_hi.w);
+        store_act4(o + 4, v, wt);
+    }
+    LWS_STAMPK(18, 3);
 }
+#undef LWS_Q2
 
 // =============================================================================================
 // First layer, C3 == 8 (stages 2 and 3), on fp32 MFMA: k_conv3d_mid8's scheme with one input channel.  Rows =
@@ -994,9 +938,10 @@ __global__ __launch_bounds__((LastCfg<C3, TD, TY, TX, FUSE>::NT)) void k_conv3d_
 // =============================================================================================
 // host side
 // =============================================================================================
+constexpr size_t MID8_PACK = 72 * 64;      // k_conv3d_mid8's fragments; k_conv3d_mid8q's 28 x 64 follow
 size_t packed_mid_weight_floats(int c3)
 {
-    if (c3 == 8) return 72 * 64;
+    if (c3 == 8) return MID8_PACK + 28 * 64;
     return (size_t)29 * c3 * c3;   // 27 taps + two all-zero taps (branch-free two-taps-ahead prefetch in k_conv3d_mid16)
 }
 
@@ -1019,6 +964,13 @@ void pack_mid_weights(const float *w, int c3, float *out)
                             out[((step >> 2) * 64 + lane) * 4 + (step & 3)] = v;
                         }
                     }
+        // k_conv3d_mid8q: register `tap`, lane 4 (2 cin + cg) + i  ->  W[4 cg + i][cin][tap]; stored [tap / 4][lane][tap % 4]
+        float *oq = out + MID8_PACK;
+        for (int tap = 0; tap < 28; ++tap)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int k = lane >> 2, i = lane & 3, cin = k >> 1, cg = k & 1;
+                oq[((tap >> 2) * 64 + lane) * 4 + (tap & 3)] = tap < 27 ? w[((4 * cg + i) * 8 + cin) * 27 + tap] : 0.0f;
+            }
         return;
     }
     const int Q = c3 / 16, MT = c3 / 16;
@@ -1103,14 +1055,10 @@ static int mid16_launch(const Stage3d &s, int layer, const float *in, float *out
                         hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     using Cfg = Mid16Cfg<C3, TD, TY, WR, WM>;
-    static unsigned attr_devs = 0;                     // one bit per device: the attribute is per (function, device)
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    const bool attr_set = (attr_devs >> (dev_ & 31)) & 1u;
-    if (!attr_set) {
-        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3d_mid16<C3, TD, TY, WR, WM>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr_devs |= 1u << (dev_ & 31);
+    static std::atomic<uint64_t> attr_done{0};
+    {
+        const int rc_ = ensure_dyn_lds(attr_done, reinterpret_cast<const void *>(&k_conv3d_mid16<C3, TD, TY, WR, WM>), Cfg::LDS_BYTES);
+        if (rc_) return rc_;
     }
     const int tiles_x = cdiv(w, 16), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
@@ -1137,14 +1085,10 @@ static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out,
                        hipStream_t st)
 {
     using Cfg = Mid8Cfg<TD, TY>;
-    static unsigned attr_devs = 0;                     // one bit per device: the attribute is per (function, device)
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    const bool attr_set = (attr_devs >> (dev_ & 31)) & 1u;
-    if (!attr_set && Cfg::LDS_BYTES > 48 * 1024) {
-        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3d_mid8<TD, TY>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr_devs |= 1u << (dev_ & 31);
+    static std::atomic<uint64_t> attr_done{0};
+    if (Cfg::LDS_BYTES > 48 * 1024) {
+        const int rc_ = ensure_dyn_lds(attr_done, reinterpret_cast<const void *>(&k_conv3d_mid8<TD, TY>), Cfg::LDS_BYTES);
+        if (rc_) return rc_;
     }
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
@@ -1154,14 +1098,19 @@ static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out,
     return LWS_OK;
 }
 
-template <int TY, int WP>
-static int mid8s_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w, hipStream_t st)
+template <int TD, int TY>
+static int mid8q_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w, hipStream_t st)
 {
-    using Cfg = Mid8sCfg<TY, WP>;
-    const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY);
-    dim3 grid(tiles_x * tiles_y, B), block(Cfg::NT);
-    hipLaunchKernelGGL((k_conv3d_mid8s<TY, WP>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w, s.layers[layer + 1].bn_s,
-                       s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, /*wt=*/0);
+    using Cfg = Mid8qCfg<TD, TY>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (Cfg::LDS_BYTES > 48 * 1024) {
+        const int rc_ = ensure_dyn_lds(attr_done, reinterpret_cast<const void *>(&k_conv3d_mid8q<TD, TY>), Cfg::LDS_BYTES);
+        if (rc_) return rc_;
+    }
+    const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
+    dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
+    hipLaunchKernelGGL((k_conv3d_mid8q<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w + MID8_PACK,
+                       s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, /*wt=*/0);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -1174,14 +1123,7 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
         case 8: {
             // (whole-D tiles, 9 rows per wave, measured r01: 19.3 vs 17.0 us at B=1 256x512 -- one wave per SIMD cannot
             // overlap its own staging with its MFMAs, three co-resident small workgroups can)
-            // d-streaming form (option "mid8_stream").  Measured r02 (tools/sbench.py, us per launch, 3-deep tiles vs d-streaming):
-            // stage 3 (9 x 128 x 256) 19.1 vs 22.0 at B = 1, 31.4 vs 30.9 at B = 2, 105.7 vs 107.1 at B = 8; stage 2
-            // (9 x 64 x 128) 8.8 vs 20.2 at B = 1 (64 workgroups), 32.7 vs 32.2 at B = 8; 8 x 368x1232: 371.5 vs 377.4.  Both forms
-            // level off at ~77 TF useful = 103 TF issued (0.65 of the fp32-MFMA peak): the staging phases were not the limit.
-            // mid8_stream = 2: 8 waves per workgroup, one plane per wave (two waves per SIMD cover each other's latencies):
-            // stage 3 19.3 at B = 1, 29.4 at B = 2, 53.9 at B = 4, 101.8 at B = 8, 379.7 at 8 x 368x1232 -- within +-3 % of the tiles.
-            if (s.mid8_stream == 1 && D >= 3) return mid8s_launch<4, 1>(s, layer, act_in, act_out, B, D, h, w, st);
-            if (s.mid8_stream == 2 && D >= 3) return mid8s_launch<4, 2>(s, layer, act_in, act_out, B, D, h, w, st);
+            if (s.mid8_form == 1) return mid8q_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
             return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
         }
         case 16: return mid16_launch<16, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
@@ -1198,14 +1140,10 @@ static int last_launch(const Stage3d &s, const float *act, const float *skip, fl
                        int B, int D, int h, int w, hipStream_t st)
 {
     using Cfg = LastCfg<C3, TD, TY, TX, FUSE>;
-    static unsigned attr_devs = 0;                     // one bit per device: the attribute is per (function, device)
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    const bool attr_set = (attr_devs >> (dev_ & 31)) & 1u;
-    if (!attr_set && Cfg::LDS_BYTES > 48 * 1024) {
-        LWS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3d_last<C3, TD, TY, TX, FUSE>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr_devs |= 1u << (dev_ & 31);
+    static std::atomic<uint64_t> attr_done{0};
+    if (Cfg::LDS_BYTES > 48 * 1024) {
+        const int rc_ = ensure_dyn_lds(attr_done, reinterpret_cast<const void *>(&k_conv3d_last<C3, TD, TY, TX, FUSE>), Cfg::LDS_BYTES);
+        if (rc_) return rc_;
     }
     const int tiles_x = cdiv(w, TX), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);

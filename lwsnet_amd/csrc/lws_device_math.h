@@ -5,6 +5,15 @@
 
 namespace lws {
 
+// XCD-aware block -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD a
+// contiguous run of tiles; neighbouring tiles then find each other's halo voxels in the same L2.
+// Speed only: any placement is correct.
+__device__ __forceinline__ int xcd_tile(int b, int nb)
+{
+    const int q = nb >> 3, r = nb & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 // exp(x) for x <= 0 from IEEE mul / fma / rint only (Cephes expf polynomial), so the result is a
 // pure function of the float32 input on any IEEE machine; returns 0 below -80 (e^-80 ~ 1.8e-35).
 __device__ __forceinline__ float lws_expf(float x)

@@ -162,6 +162,27 @@ class LWSNet:
         _lib.check(_lib.load().lws_get_option(self._h, name.encode(), ctypes.byref(v)), "lws_get_option")
         return v.value
 
+    # ---- several forwards in flight (include/lwsnet_hip.h: lws_pool_*) --------------------------
+    def pool(self, workers=3, side_streams=False):
+        """A pool of `workers` host threads inside the HIP library, each with its own clone of this model (shared
+        parameters, private workspace) and one HIP stream: batch-1 forwards are launch-latency-bound chains of ~35
+        dependent kernels, and keeping a few of them in flight overlaps them.  Bit-identical to forward()."""
+        if self._params is None:
+            raise RuntimeError("set_state_dict() must be called before pool()")
+        return ForwardPool(self, int(workers), bool(side_streams))
+
+    def map(self, pairs, workers=3):
+        """`[model(l, r) for l, r in pairs]` with up to 2 x `workers` forwards in flight; yields the four stage maps of
+        each pair in order (device tensors, complete when yielded)."""
+        with self.pool(workers) as pool:
+            window = []
+            for left, right in pairs:
+                window.append(pool.submit(left, right))
+                if len(window) >= 2 * workers:
+                    yield window.pop(0).result()
+            for job in window:
+                yield job.result()
+
     def _device_ctx(self):
         if self.device is None:
             import contextlib
@@ -187,3 +208,75 @@ class LWSNet:
             return [DisparityTensor.wrap(p) for p in ops.forward(self._h, left, right)]      # models.py:106-164
 
     __call__ = forward
+
+
+class _PoolJob:
+    def __init__(self, pool, ticket, keep, outs):
+        self._pool, self._ticket, self._keep, self._outs = pool, ticket, keep, outs
+
+    def result(self):
+        """Blocks until the four stage maps are complete in device memory and returns them."""
+        self._pool._wait(self._ticket)
+        self._keep = None
+        return [DisparityTensor.wrap(o) for o in self._outs]
+
+
+class ForwardPool:
+    """Python face of lws_pool (see LWSNet.pool).  `submit` returns at once; `.result()` of the job waits for it."""
+
+    def __init__(self, model, workers, side_streams=False):
+        self._model = model                     # keeps the source handle alive
+        self._lib = _lib.load()
+        self._p = ctypes.c_void_p()
+        self._shape = None
+        with torch.cuda.device(model.device):
+            _lib.check(self._lib.lws_pool_create(model._h, workers, _lib.LWS_POOL_SIDE_STREAMS if side_streams else 0,
+                                                 ctypes.byref(self._p)), "lws_pool_create")
+        self.workers = workers
+
+    def reserve(self, B, H, W):
+        with torch.cuda.device(self._model.device):
+            _lib.check(self._lib.lws_pool_reserve(self._p, int(B), int(H), int(W)), "lws_pool_reserve")
+        self._shape = (B, H, W)
+        return self
+
+    def submit(self, left_input, right_input, out=None):
+        m = self._model
+        left, right = m._input(left_input, "left_input"), m._input(right_input, "right_input")
+        if left.shape != right.shape:
+            raise ValueError(f"left/right shapes differ: {tuple(left.shape)} vs {tuple(right.shape)}")
+        B, _, H, W = left.shape
+        check_size(H, W, m.maxdisplist[0])
+        outs = out if out is not None else [torch.empty((B, 1, H, W), device=left.device, dtype=torch.float32) for _ in range(4)]
+        ticket = ctypes.c_int64(-1)
+        with torch.cuda.device(m.device):
+            if self._shape is None or B > self._shape[0] or (H, W) != tuple(self._shape[1:]):
+                self.reserve(B, H, W)            # first use / new geometry: allocate before anything is in flight
+            ptrs = (ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs])
+            after = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(self._lib.lws_pool_submit(self._p, ctypes.c_void_p(left.data_ptr()), ctypes.c_void_p(right.data_ptr()),
+                                                 B, H, W, ptrs, after, ctypes.byref(ticket)), "lws_pool_submit")
+        return _PoolJob(self, ticket.value, (left, right), outs)
+
+    def _wait(self, ticket):
+        _lib.check(self._lib.lws_pool_wait(self._p, ctypes.c_int64(ticket)), "lws_pool_wait")
+
+    def wait_all(self):
+        _lib.check(self._lib.lws_pool_wait_all(self._p), "lws_pool_wait_all")
+
+    def close(self):
+        if self._p:
+            self._lib.lws_pool_destroy(self._p)
+            self._p = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

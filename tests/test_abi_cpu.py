@@ -26,7 +26,7 @@ def test_header_and_prototypes_agree():
 def test_library_exports_every_symbol(hip_lib):
     for name in _declared():
         assert hasattr(hip_lib, name), name
-    assert hip_lib.lws_abi_version() == 4
+    assert hip_lib.lws_abi_version() == 5
 
 
 def _create(lib, **kw):
@@ -102,7 +102,7 @@ def test_options_validate_names_and_ranges(hip_lib):
     rc, h = _create(hip_lib)
     assert rc == 0
     v = ctypes.c_int(123)
-    for name, default in [(b"left_at", -1), (b"split_heads", -1), (b"fuse_shift", 1), (b"fuse_first", 1), (b"defer_upsample", 1), (b"fuse_dws", 0), (b"mid8_stream", 0)]:
+    for name, default in [(b"left_at", -1), (b"split_heads", -1), (b"fuse_shift", 1), (b"fuse_first", 1), (b"defer_upsample", 1), (b"mid8_form", 0), (b"side_streams", 1), (b"ref_order", 0)]:
         assert hip_lib.lws_get_option(h, name, ctypes.byref(v)) == 0 and v.value == default
     assert hip_lib.lws_set_option(h, b"left_at", 2) == 0
     assert hip_lib.lws_get_option(h, b"left_at", ctypes.byref(v)) == 0 and v.value == 2
@@ -111,3 +111,46 @@ def test_options_validate_names_and_ranges(hip_lib):
     assert hip_lib.lws_set_option(h, b"bogus", 1) == _lib.LWS_ERR_INVALID
     assert b"unknown option" in hip_lib.lws_last_error()
     hip_lib.lws_destroy(h)
+
+
+def test_handle_refuses_a_foreign_current_device(hip_lib):
+    """include/lwsnet_hip.h: a handle belongs to one HIP device and every GPU-touching call checks that it is the calling
+    thread's current device (a launch from another device would run on foreign pointers).  Host-side check: it fires
+    before any HIP work, so it is testable without a GPU -- rebind the handle to device 5 (legal before anything is
+    allocated) and call in from whatever device is current here (-1 on a CPU box, 0 on the one-GPU box)."""
+    rc, h = _create(hip_lib)
+    assert rc == 0
+    v = ctypes.c_int(99)
+    assert hip_lib.lws_get_option(h, b"device", ctypes.byref(v)) == 0 and v.value in (-1, 0)
+    assert hip_lib.lws_set_option(h, b"device", -3) == _lib.LWS_ERR_INVALID
+    assert hip_lib.lws_set_option(h, b"device", 5) == 0
+    assert hip_lib.lws_reserve(h, 1, 64, 256) == _lib.LWS_ERR_INVALID
+    msg = hip_lib.lws_last_error()
+    assert b"belongs to HIP device 5" in msg and b"current device" in msg
+    with pytest.raises(ValueError, match="belongs to HIP device 5"):
+        _lib.check(_lib.LWS_ERR_INVALID)
+    z = np.zeros((1, 3, 64, 256), np.float32)
+    outs = (ctypes.c_void_p * 4)(*[z.ctypes.data] * 4)
+    assert hip_lib.lws_forward(h, z.ctypes.data, z.ctypes.data, 1, 64, 256, outs, None) == _lib.LWS_ERR_INVALID
+    assert b"lws_forward: the handle belongs to HIP device 5" in hip_lib.lws_last_error()
+    assert hip_lib.lws_finalize(h) == _lib.LWS_ERR_INVALID          # device check comes before the state check
+    # size errors still win over the device error (pure argument validation comes first)
+    assert hip_lib.lws_reserve(h, 1, 375, 1242) == _lib.LWS_ERR_INVALID
+    assert b"unsupported input size" in hip_lib.lws_last_error()
+    assert hip_lib.lws_destroy(h) == 0
+
+
+def test_clone_and_pool_validate_on_host(hip_lib):
+    """lws_clone / lws_pool_* argument and state errors need no GPU."""
+    rc, h = _create(hip_lib)
+    assert rc == 0
+    c = ctypes.c_void_p()
+    assert hip_lib.lws_clone(h, ctypes.byref(c)) == _lib.LWS_ERR_STATE         # not finalized
+    assert b"not been finalized" in hip_lib.lws_last_error()
+    p = ctypes.c_void_p()
+    assert hip_lib.lws_pool_create(h, 0, 0, ctypes.byref(p)) == _lib.LWS_ERR_INVALID
+    assert hip_lib.lws_pool_create(h, 3, 8, ctypes.byref(p)) == _lib.LWS_ERR_INVALID
+    assert hip_lib.lws_pool_create(h, 3, 0, ctypes.byref(p)) == _lib.LWS_ERR_STATE
+    assert hip_lib.lws_pool_workers(None) == 0 and hip_lib.lws_pool_destroy(None) == 0
+    assert hip_lib.lws_pool_wait_all(None) == _lib.LWS_ERR_INVALID
+    assert hip_lib.lws_destroy(h) == 0

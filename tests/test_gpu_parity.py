@@ -103,13 +103,13 @@ def test_conv3d_stack_bitexact(dev, model, stage, shape):
     from oracle import c_oracle as C
     c = (np.random.default_rng(stage + 1).random(shape) * 12.0).astype(np.float32)
     want = C.conv3d_stack(c, model.state_dict(), stage)
-    for stream in ((0, 1, 2) if stage > 0 else (0,)):        # 8 -> 8 layers: 3-deep tiles and the two d-streaming forms
-        model.set_option("mid8_stream", stream)
+    for form in ((0, 1) if stage > 0 else (0,)):        # 8 -> 8 layers: 16x16x4 parity-row tiles and the 4x4x1_16B form
+        model.set_option("mid8_form", form)
         try:
             got = ops.conv3d_stack(model._h, stage, cu(c, dev))
         finally:
-            model.set_option("mid8_stream", 0)
-        assert_bits(got, want, f"conv3d_stack stage {stage} {shape} mid8_stream={stream}")
+            model.set_option("mid8_form", 0)
+        assert_bits(got, want, f"conv3d_stack stage {stage} {shape} mid8_form={form}")
 
 
 @pytest.mark.parametrize("stage", [0, 1])
@@ -190,20 +190,20 @@ def test_feature_extraction_golden(dev, model):
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 64, 256), (2, 40, 72), (1, 136, 152), (1, 63, 255)])
-@pytest.mark.parametrize("fuse_dws", [0, 1])
-def test_refine_bitexact(dev, model, B, H, W, fuse_dws):
-    """fuse_dws = 1: the depthwise-separable blocks run pairwise in k_ref_dws2 (dilation pairs (2,4), (8,16), (4,8), (8,4),
-    (2,1)): the same fmaf / MFMA chains, so the same bits."""
+@pytest.mark.parametrize("ref_order", [0, 1, 2])
+def test_refine_bitexact(dev, model, B, H, W, ref_order):
+    """ref_order: block -> tile order of the phase-grid kernels (dispatch order / XCD-contiguous / phase slowest): the
+    tiles partition the image under every order, so the bits cannot change."""
     from lwsnet_amd import ops
     from oracle import c_oracle as C
     rng = np.random.default_rng(9)
     left = rng.standard_normal((B, 3, H, W)).astype(np.float32)
     pred3 = (rng.random((B, 1, H, W)) * 150.0).astype(np.float32)
-    model.set_option("fuse_dws", fuse_dws)
+    model.set_option("ref_order", ref_order)
     try:
         got = ops.refine(model._h, cu(left, dev), cu(pred3, dev))
     finally:
-        model.set_option("fuse_dws", 0)
+        model.set_option("ref_order", 0)
     assert_bits(got, C.refine(left, pred3, model.state_dict()), "refine")
 
 
@@ -274,9 +274,9 @@ def test_forward_repeatable_batch8(dev, model):
 
 
 OPTION_PLANS = [{"left_at": 0}, {"left_at": 2}, {"split_heads": 1}, {"split_heads": 0}, {"fuse_shift": 0},
-                {"fuse_first": 0}, {"defer_upsample": 0}, {"fuse_dws": 1}, {"mid8_stream": 1},
-                {"left_at": 2, "split_heads": 1},
-                {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0, "fuse_dws": 1}]
+                {"fuse_first": 0}, {"defer_upsample": 0}, {"mid8_form": 1}, {"ref_order": 1}, {"ref_order": 2},
+                {"side_streams": 0}, {"side_streams": 0, "left_at": 0}, {"left_at": 2, "split_heads": 1},
+                {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0, "mid8_form": 1}]
 
 
 @pytest.mark.parametrize("plan", OPTION_PLANS, ids=lambda p: ",".join(f"{k}={v}" for k, v in p.items()))
@@ -342,6 +342,53 @@ def test_handles_on_their_own_threads_and_streams(dev, hip_lib):
         t.join()
     torch.cuda.synchronize()
     assert not bad, bad
+
+
+@pytest.mark.parametrize("side_streams", [False, True])
+def test_pool_returns_the_bits_of_forward(dev, model, side_streams):
+    """lws_pool (include/lwsnet_hip.h): C++ worker threads, each with a clone of the model (shared parameters) and one HIP
+    stream, keep several forwards in flight.  Every job's four stage maps equal model(left, right) bit for bit, in order,
+    across ragged geometry changes (the pool re-reserves) and more jobs than job slots (tickets recycle)."""
+    left, right = make_batch(6, 64, 256, 120)
+    lt, rt = cu(left, dev), cu(right, dev)
+    want = [[p.clone() for p in model(lt[i:i + 1], rt[i:i + 1])] for i in range(6)]
+    with model.pool(workers=3, side_streams=side_streams) as pool:
+        jobs = [pool.submit(lt[i % 6:i % 6 + 1], rt[i % 6:i % 6 + 1]) for i in range(40)]     # 40 > 4 x 3 slots
+        for i, job in enumerate(jobs):
+            got = job.result()
+            assert all(torch.equal(a, b) for a, b in zip(got, want[i % 6])), f"job {i}"
+        assert all(torch.equal(a, b) for a, b in zip(jobs[0].result(), want[0]))              # a ticket may be waited for again
+        # a batch of 2 and another geometry through the same pool
+        got2 = pool.submit(lt[2:4], rt[2:4]).result()
+        assert all(torch.equal(g[0], w[0]) and torch.equal(g[1], w2[0]) for g, w, w2 in zip(got2, want[2], want[3]))
+        l3, r3 = make_batch(1, 40, 264, 5)
+        got3 = pool.submit(l3, r3).result()
+        assert all(torch.equal(a, b) for a, b in zip(got3, model(l3, r3)))
+        with pytest.raises(ValueError):
+            pool.submit(np.zeros((1, 3, 375, 1242), np.float32), np.zeros((1, 3, 375, 1242), np.float32))
+    # LWSNet.map: the generator face of the same pool
+    outs = list(model.map(((lt[i:i + 1], rt[i:i + 1]) for i in range(6)), workers=2))
+    assert len(outs) == 6 and all(torch.equal(a, b) for o, w in zip(outs, want) for a, b in zip(o, w))
+
+
+def test_clone_shares_parameters(dev, model, hip_lib):
+    """lws_clone: a second handle on the same parameter slab; it refuses set_tensor / finalize and returns the same bits."""
+    import ctypes
+    from lwsnet_amd import _lib, ops
+    c = ctypes.c_void_p()
+    _lib.check(hip_lib.lws_clone(model._h, ctypes.byref(c)), "lws_clone")
+    try:
+        left, right = make_batch(2, 64, 256, 7)
+        got = ops.forward(c, cu(left, dev), cu(right, dev))
+        assert all(torch.equal(a, b) for a, b in zip(got, model(left, right)))
+        assert hip_lib.lws_finalize(c) == _lib.LWS_ERR_STATE
+        w = np.zeros((32, 3, 3, 3), np.float32)
+        shp = (ctypes.c_int64 * 4)(32, 3, 3, 3)
+        assert hip_lib.lws_set_tensor(c, b"refinement1_left.0.weight", w.ctypes.data_as(_lib.c_float_p), shp, 4) == _lib.LWS_ERR_STATE
+    finally:
+        hip_lib.lws_destroy(c)
+    p = model(left, right)                     # the source handle is untouched by the clone's destruction
+    assert all(torch.equal(a, b) for a, b in zip(got, p))
 
 
 def test_forward_repeatable(dev, model):

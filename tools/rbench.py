@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel timing of the refinement (lws_refine) on the GPU, fused depthwise pairs on and off (development aid).
+"""Per-kernel timing of the refinement (lws_refine) on the GPU, for each block -> tile order of the phase-grid kernels (option ref_order; development aid).
 
     python tools/rbench.py [--batch B] [--size HxW] [--iters N]"""
 import argparse
@@ -29,8 +29,8 @@ def main():
     left = torch.randn((a.batch, 3, H, W), device=dev)
     p3 = torch.rand((a.batch, 1, H, W), device=dev) * 100
     outs = {}
-    for fuse in (0, 1):
-        m.set_option("fuse_dws", fuse)
+    for fuse in (0, 1, 2):
+        m.set_option("ref_order", fuse)
         for _ in range(5):
             outs[fuse] = ops.refine(m._h, left, p3)
         torch.cuda.synchronize()
@@ -47,11 +47,11 @@ def main():
         cnt = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
         _lib.check(lib.lws_profile_read(m._h, tot, cnt))
         _lib.check(lib.lws_profile_enable(m._h, 0))
-        print(f"fuse_dws={fuse} B={a.batch} {H}x{W}: wall {wall * 1e6:.1f} us per lws_refine; kernels (with event overhead):")
+        print(f"ref_order={fuse} B={a.batch} {H}x{W}: wall {wall * 1e6:.1f} us per lws_refine; kernels (with event overhead):")
         for kc in range(_lib.LWS_KC_COUNT):
             if cnt[kc]:
                 print(f"   {lib.lws_kernel_class_name(kc).decode():12s} x{cnt[kc] // a.iters:2d} avg {tot[kc] / cnt[kc] * 1e3:7.2f} us")
-    print("bitwise equal:", bool(torch.equal(outs[0], outs[1])))
+    print("bitwise equal:", bool(torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])))
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Conv3D stack of one stage alone (lws_conv3d_stack): per-kernel-class averages, 3-deep tiles vs d-streaming (dev aid)."""
+"""Conv3D stack of one stage alone (lws_conv3d_stack): per-kernel-class averages, 16x16x4 parity-row tiles (mid8_form 0) vs 4x4x1_16B (mid8_form 1) (dev aid)."""
 import argparse, ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,8 +17,8 @@ m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
 lib = _lib.load()
 for stage, (D, div) in ((1, (9, 4)), (2, (9, 2))):
     c = torch.rand((a.batch, D, H // div, W // div), device=dev) * 12
-    for stream in (0, 1, 2):
-        m.set_option("mid8_stream", stream)
+    for form in (0, 1):
+        m.set_option("mid8_form", form)
         for _ in range(5):
             ops.conv3d_stack(m._h, stage, c)
         torch.cuda.synchronize()
@@ -33,4 +33,4 @@ for stage, (D, div) in ((1, (9, 4)), (2, (9, 2))):
         kc = 4
         avg = tot[kc] / cnt[kc] * 1e3
         gf = 2 * 27 * 8 * 8 * a.batch * D * (H // div) * (W // div)
-        print(f"stage {stage + 1} B={a.batch} mid8_stream={stream}: k_conv3d_mid8 avg {avg:7.2f} us = {gf / avg / 1e6:6.1f} TF useful")
+        print(f"stage {stage + 1} B={a.batch} mid8_form={form}: k_conv3d_mid8 avg {avg:7.2f} us = {gf / avg / 1e6:6.1f} TF useful")

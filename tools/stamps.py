@@ -1,12 +1,12 @@
 """Diagnostic: per-workgroup phase stamps (s_memtime, shader cycles) of one kernel.
 
     python tools/stamps.py <kernel> [batch]     # rebuilds the library with -DLWS_STAMPS=<id>, runs, prints medians
-kernels: mid16 mid8s2 mid8s3 last1 last3 dws conv64 feat pair0..pair3 ref_last warp2 warp3
+kernels: mid16 mid8_2 mid8_3 mid8q2 mid8q3 last1 last3 first1 first3 dws conv64 feat pair0..pair3 ref_last warp2 warp3
 Slots: 0..3 = phase boundaries as placed in the kernel source (LWS_STAMPK)."""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, '/root/repo')
 KERNELS = {  # name: (stamp id, translation unit, driver, arg)
-    "mid16": (1, "conv3d", "stack", 0), "mid8s2": (2, "conv3d", "stack", 1), "mid8s3": (2, "conv3d", "stack", 2),
+    "mid16": (1, "conv3d", "stack", 0), "mid8_2": (2, "conv3d", "stack", 1), "mid8_3": (2, "conv3d", "stack", 2),
     "last1": (3, "conv3d", "stack", 0), "last3": (3, "conv3d", "stack", 2),
     "first1": (4, "conv3d", "stack", 0), "first3": (4, "conv3d", "stack", 2),
     
@@ -14,7 +14,7 @@ KERNELS = {  # name: (stamp id, translation unit, driver, arg)
     "feat": (7, "conv2d", "feat", None), "pair0": (13, "conv2d", "feat", None), "pair1": (14, "conv2d", "feat", None),
     "pair2": (15, "conv2d", "feat", None), "pair3": (16, "conv2d", "feat", None), "ref_last": (9, "conv2d", "refine", None),
     "warp2": (10, "volume", "stages", None), "warp3": (10, "volume", "stages", None),
-    "dws2": (17, "conv2d", "refine", None), "mid8s3": (18, "conv3d", "stack", 2), "mid8s2": (18, "conv3d", "stack", 1),
+    "mid8q3": (18, "conv3d", "stack", 2), "mid8q2": (18, "conv3d", "stack", 1),
 }
 what = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -28,10 +28,8 @@ from lwsnet_amd.weights import default_args, make_state_dict
 dev = torch.device('cuda:0')
 m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
 lib = ctypes.CDLL(_lib.LIB_PATH)
-if what == "dws2":
-    m.set_option("fuse_dws", 1)
 if kid == 18:
-    m.set_option("mid8_stream", 1)
+    m.set_option("mid8_form", 1)
 if driver == "stack":
     shape = [(B, 24, 32, 64), (B, 9, 64, 128), (B, 9, 128, 256)][arg]
     c = torch.rand(shape, device=dev) * 12
