@@ -486,7 +486,7 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
                                                                         int tiles_x, int tiles_y, int wt)
 {
     using Cfg = Mid8qCfg<TD, TY>;
-    constexpr int HY = Cfg::HY, HX = Cfg::HX, NP = Cfg::NP, NT = Cfg::NT, SITER = Cfg::SITER;
+    constexpr int HY = Cfg::HY, HX = Cfg::HX, NP = Cfg::NP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4 *lds4 = reinterpret_cast<float4 *>(lds);
 
@@ -501,18 +501,30 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
     const float *inb = in + (int64_t)b * D * h * w * 8;
     LWS_STAMPK(18, 0);
 
-    // ---- stage: item = (voxel, channel half) = 16 B; all global loads of a thread are in flight before the first
-    //      LDS write; out-of-volume voxels become literal zeros (the convolution's padding)
-    float4 c[SITER];
-    bool okv[SITER];
+    // ---- stage, one halo ROW per wave-instruction: a row of the halo tile is HX voxels x 8 channels = 2 HX contiguous
+    //      float4 in global memory, so lane j of item group (row, j) loads base_row + 16 j bytes and everything about the
+    //      row -- its (d, y), its validity, its global base, its LDS offset -- is wave-uniform (SGPR arithmetic; the
+    //      MFMAs below hold the vector issue port 8 cycles of every 10, so per-item VALU index math is paid in full:
+    //      the per-item form of k_conv3d_mid8 cost ~35 VALU per 16 bytes here).  Rows are dealt round-robin to the waves;
+    //      all loads of a wave are in flight before its first LDS write; out-of-volume voxels become literal zeros.
+    constexpr int NROW = Cfg::HD * HY, NW = Cfg::NW, RITER = (NROW + NW - 1) / NW, RI = 2 * HX;   // RI float4 per row
+    static_assert(RI > 64 && RI <= 128, "a row is two wave-loads");
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int j0 = lane, j1 = lane + 64;                    // the lane's two items of a row: voxel j >> 1, half j & 1
+    const int gx0 = x0 - 1 + (j0 >> 1), gx1 = x0 - 1 + (j1 >> 1);
+    const bool okx0 = gx0 >= 0 && gx0 < w, okx1 = j1 < RI && gx1 >= 0 && gx1 < w;
+    const int lo0 = (j0 & 1) * NP + (j0 >> 1), lo1 = (j1 & 1) * NP + (j1 >> 1);      // LDS slot inside the row
+    float4 c0[RITER], c1[RITER];
+    bool rok[RITER];
 #pragma unroll
-    for (int i = 0; i < SITER; ++i) {
-        const int it = tid + i * NT;
-        const int half = it & 1, v = it >> 1;
-        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
-        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        okv[i] = it < Cfg::ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        c[i] = *reinterpret_cast<const float4 *>(inb + (okv[i] ? (((int64_t)gd * h + gy) * w + gx) * 8 + half * 4 : 0));
+    for (int k = 0; k < RITER; ++k) {
+        const int row = wv + k * NW;                        // wave-uniform
+        const int hd = row / HY, hy = row - hd * HY;
+        const int gd = d0 + hd - 1, gy = y0 + hy - 1;
+        rok[k] = row < NROW && gd >= 0 && gd < D && gy >= 0 && gy < h;
+        const float *rb = inb + (rok[k] ? (((int64_t)gd * h + gy) * w + (x0 - 1)) * 8 : 0);      // (may point before the
+        c0[k] = *reinterpret_cast<const float4 *>((rok[k] && okx0) ? rb + 4 * j0 : inb);          //  row: guarded per lane)
+        c1[k] = *reinterpret_cast<const float4 *>((rok[k] && okx1) ? rb + 4 * j1 : inb);
     }
     // the 27 A registers of this lane ([tap / 4][lane][tap % 4]) and the next layer's BatchNorm (wave-uniform)
     float wa[28];
@@ -526,10 +538,14 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
     }
     const float4 s_lo = *reinterpret_cast<const float4 *>(bn_s), s_hi = *reinterpret_cast<const float4 *>(bn_s + 4);
     const float4 t_lo = *reinterpret_cast<const float4 *>(bn_t), t_hi = *reinterpret_cast<const float4 *>(bn_t + 4);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < SITER; ++i) {
-        const int it = tid + i * NT;
-        if (it < Cfg::ITEMS) lds4[(it & 1) * NP + (it >> 1)] = okv[i] ? c[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < RITER; ++k) {
+        const int row = wv + k * NW;
+        if (row < NROW) {
+            lds4[row * HX + lo0] = (rok[k] && okx0) ? c0[k] : z4;
+            if (j1 < RI) lds4[row * HX + lo1] = (rok[k] && okx1) ? c1[k] : z4;
+        }
     }
     __syncthreads();
     LWS_STAMPK(18, 1);

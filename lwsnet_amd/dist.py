@@ -50,7 +50,7 @@ def gather_pairs(local, counts=None, dst=0, group=None):
     Equal shards use one `gather`; ragged shards are padded to the largest shard first."""
     if not dist.is_initialized():
         return local
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    world, rank = dist.get_world_size(group), dist.get_rank()        # (global rank: `dst` is one)
     if counts is None:
         counts = [local.shape[0]] * world
     bmax = max(counts)
@@ -70,7 +70,8 @@ def gather_async(local, bufs, dst=0, group=None):
     """The ONE collective of the path as bench.py issues it per step: equal shards, buffers pre-allocated on `dst`
     (`bufs`: list of world tensors there, None elsewhere), asynchronous -- RCCL runs it on its own stream behind this
     step's kernels so it overlaps the next step.  Returns the work handle (wait() before reading `bufs`)."""
-    return dist.gather(local.contiguous(), bufs if dist.get_rank(group) == dst else None, dst=dst, group=group, async_op=True)
+    # `dst` of dist.gather is a GLOBAL rank: compare with the global rank, not the group-local one
+    return dist.gather(local.contiguous(), bufs if dist.get_rank() == dst else None, dst=dst, group=group, async_op=True)
 
 
 def sharded_forward(model_fn, left, right, dst=0):

@@ -14,7 +14,7 @@ def error_3px(disp, gt, maxdisp=192):
 
 
 def end_point_error(disp, gt, maxdisp=192):
-    """SceneFlow EPE, /root/reference/train.py:202-210: mean |d - gt| over gt < maxdisp."""
+    """SceneFlow EPE, /root/reference/train.py:179 (mask = gt < maxdisp) and :190 (mean |d - gt| over the mask)."""
     disp = np.asarray(disp, dtype=np.float64)
     gt = np.asarray(gt, dtype=np.float64)
     mask = gt < maxdisp

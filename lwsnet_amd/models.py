@@ -193,7 +193,9 @@ class LWSNet:
     def _input(self, x, name):
         return as_input(x, name, self.device)
 
-    def forward(self, left_input, right_input):
+    def forward(self, left_input, right_input, out=None):
+        """model(left, right) -> [pred1 .. pred4] (models.py:106-164).  `out` (not in the reference): optional list of
+        four pre-allocated [B,1,H,W] device tensors (None entries are allocated) that receive the stage maps."""
         if self.device is None:
             raise RuntimeError("no HIP device is available and lwsnet_amd has no CPU fallback")
         if self._params is None:
@@ -205,7 +207,7 @@ class LWSNet:
         B, _, H, W = left.shape
         check_size(H, W, self.maxdisplist[0])
         with torch.cuda.device(self.device):
-            return [DisparityTensor.wrap(p) for p in ops.forward(self._h, left, right)]      # models.py:106-164
+            return [DisparityTensor.wrap(p) for p in ops.forward(self._h, left, right, out)]      # models.py:106-164
 
     __call__ = forward
 

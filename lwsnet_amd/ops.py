@@ -151,11 +151,21 @@ def refine(handle, left, pred3):
     return out
 
 
-def forward(handle, left, right):
-    """LWSNet.forward (models/models.py:106-164): list of 4 x [B,1,H,W]."""
+def forward(handle, left, right, out=None):
+    """LWSNet.forward (models/models.py:106-164): list of 4 x [B,1,H,W].  `out` (optional): a list of four destinations;
+    entries that are None are allocated here, the others must be contiguous float32 [B,1,H,W] device tensors (a slot of
+    a staging buffer, say) and are written in place."""
     l, r = _dev(left, "left"), _dev(right, "right")
     B, _, H, W = l.shape
-    preds = [torch.empty((B, 1, H, W), device=l.device, dtype=torch.float32) for _ in range(4)]
+    preds = []
+    for s in range(4):
+        t = out[s] if out is not None else None
+        if t is None:
+            t = torch.empty((B, 1, H, W), device=l.device, dtype=torch.float32)
+        elif not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                  and tuple(t.shape) == (B, 1, H, W)):
+            raise ValueError(f"out[{s}] must be a contiguous float32 device tensor of shape {(B, 1, H, W)}")
+        preds.append(t)
     arr = ctypes.c_void_p * 4
     lib = _lib.load()
     with torch.cuda.device(l.device):

@@ -508,7 +508,11 @@ def test_forward_matches_literal_oracle(dev, model):
     err = [float(np.abs(pred[s].cpu().numpy() - g[f"pred{s}"]).max()) for s in range(4)]
     print("max-abs vs literal oracle per stage:", err)
     assert err[0] < 1e-3, err                       # north_star tolerance at the stage the noise has not amplified
-    assert max(err) < 2e-2, err                     # fp32 noise floor of stages 2-4 (numerics)
+    # stages 2-4: 1.5 x the distances measured for this fixture (2.0e-4 / 8.9e-4 / 3.5e-3 / 3.4e-3 px; the HIP result is the
+    # C oracle's bit for bit, so they are constants of the arithmetic contract, not run-to-run quantities).  They sit on
+    # the float32 noise floor of the reference algorithm, above north_star's 1e-3 px at stages 3-4.
+    for s_, bound in enumerate((3.0e-4, 1.4e-3, 5.3e-3, 5.1e-3)):
+        assert err[s_] < bound, (s_, err)
     from oracle.lws_oracle import error_3px
     assert error_3px(pred[3].cpu().numpy(), np.maximum(g["pred3"], 1e-3)) == 0.0
 

@@ -1,37 +1,39 @@
-"""Build-container only: execute the reference's OWN source (/root/reference/models/models.py, imported in place) behind the
-torch-backed stand-in for its Paddle calls (tools/paddle_shim.py) and check that it still produces the committed
+"""Build-container only: execute the reference's OWN source (/root/reference/models/models.py) behind the torch-backed
+stand-in for its Paddle calls (tools/paddle_shim.py) and check that it still produces the committed
 tests/golden/ref_source_*.npz stage maps bit for bit -- i.e. the fixtures really come from the reference's text.
-Skipped where /root/reference does not exist (the GPU box); nothing from the reference is copied or travels."""
+
+The reference tree is public, untrusted content: it is never imported into the pytest process.  The check runs in a CHILD
+process (`python -B tools/check_oracle_vs_reference.py --check-fixtures ...`, no bytecode written into the read-only
+tree) and only its exit status and report are read.  Skipped where /root/reference does not exist (the GPU box) and when
+LWS_SKIP_REFERENCE_SOURCE=1.  What this pins: the transcription of control flow / wiring / names (torch-CPU kernels under
+Paddle defaults recalled from memory) -- NOT PaddlePaddle's numerics; the oracle stays "parity unpinned"."""
 import os
+import subprocess
 import sys
 
-import numpy as np
 import pytest
-import torch
 
-from conftest import ROOT, golden
+from conftest import ROOT
 
 REF = "/root/reference"
-pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "models", "models.py")),
-                                reason="the reference tree is only mounted in the build container")
+pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "models", "models.py"))
+                                or os.environ.get("LWS_SKIP_REFERENCE_SOURCE") == "1",
+                                reason="the reference tree is only mounted in the build container (or LWS_SKIP_REFERENCE_SOURCE=1)")
+
+NAMES = ["e2e_64x256", "e2e_args_32x256", "e2e_odd_63x255"]
 
 
-@pytest.mark.parametrize("name", ["e2e_64x256", "e2e_args_32x256", "e2e_odd_63x255"])
-def test_reference_source_reproduces_committed_fixture(name):
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import check_oracle_vs_reference as chk
-    from lwsnet_amd.weights import default_args, make_state_dict
-    g = golden(f"ref_source_{name}.npz")
-    args = default_args(maxdisplist=tuple(int(v) for v in g["maxdisplist"]), layers_3d=int(g["layers_3d"]),
-                        channels_3d=int(g["channels_3d"]), growth_rate=tuple(int(v) for v in g["growth_rate"]))
-    sd = make_state_dict(int(g["seed"]), args, calibrated=bool(g["calibrated"]))
-    try:
-        out, keys = chk.run_reference(REF, args, sd, g["left"], g["right"], torch.float32)
-    finally:
-        for m in [k for k in sys.modules if k == "paddle" or k.startswith("paddle.") or k == "models" or k.startswith("models.")]:
-            del sys.modules[m]                       # leave no stand-in behind for other tests
-        if REF in sys.path:
-            sys.path.remove(REF)
-    assert keys == sorted(sd.keys())                 # the 226 structured names are the reference's own
-    for i in range(4):
-        assert np.array_equal(out[i], g[f"pred{i}"]), f"{name} stage {i + 1}"
+def _tree_state(root):
+    return sorted((os.path.join(d, f), os.path.getmtime(os.path.join(d, f)), os.path.getsize(os.path.join(d, f)))
+                  for d, _, fs in os.walk(root) for f in fs)
+
+
+def test_reference_source_reproduces_committed_fixtures():
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    before = _tree_state(os.path.join(REF, "models"))
+    p = subprocess.run([sys.executable, "-B", os.path.join(ROOT, "tools", "check_oracle_vs_reference.py"), "--reference", REF,
+                        "--check-fixtures", *NAMES], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    for name in NAMES:
+        assert f"{name}: OK" in p.stdout, p.stdout
+    assert _tree_state(os.path.join(REF, "models")) == before, "the run must not write into the reference tree (bytecode)"

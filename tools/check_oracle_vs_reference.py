@@ -11,14 +11,21 @@ stand-in for the ~25 Paddle calls it makes (tools/paddle_shim.py), and
      tools/paddle_shim.py (from memory of Paddle 2.0).  They are NOT PaddlePaddle outputs: the
      oracle remains "parity unpinned" (DESIGN.md section 2).
 
-Build-container only: /root/reference does not exist on the GPU box and nothing here is imported by the product, the
-tests, bench.py or smoke().  Nothing from /root/reference is copied: the fixtures are numeric arrays.
+  3. with --check-fixtures NAME..., re-run the reference's source and compare with the COMMITTED fixtures bit for bit
+     (tests/test_reference_source_cpu.py starts this mode as a child process: the reference's files are public,
+     untrusted content, so they are never imported into the pytest process).
 
-Usage: python tools/check_oracle_vs_reference.py [--write] [--reference /root/reference]
+Build-container only: /root/reference does not exist on the GPU box and nothing here is imported by the product,
+bench.py or smoke(); the tests only ever start it as a subprocess.  Nothing from /root/reference is copied (the fixtures
+are numeric arrays) and nothing is written there (no bytecode: sys.dont_write_bytecode).
+
+Usage: python -B tools/check_oracle_vs_reference.py [--write | --check-fixtures NAME...] [--reference /root/reference]
 """
 import argparse
 import os
 import sys
+
+sys.dont_write_bytecode = True                       # /root/reference is read-only content: leave no __pycache__ in it
 
 import numpy as np
 import torch
@@ -62,12 +69,31 @@ def run_reference(ref_root, args, sd, left, right, dtype):
     return [o.numpy() for o in out], sorted(model.state_dict().keys())
 
 
+def check_fixtures(ref_root, names):
+    """The committed tests/golden/ref_source_<name>.npz must be what the reference's source produces now, bit for bit."""
+    bad = 0
+    for name in names:
+        with np.load(os.path.join(ROOT, "tests", "golden", f"ref_source_{name}.npz")) as z:
+            g = {k: z[k] for k in z.files}
+        args = default_args(maxdisplist=tuple(int(v) for v in g["maxdisplist"]), layers_3d=int(g["layers_3d"]),
+                            channels_3d=int(g["channels_3d"]), growth_rate=tuple(int(v) for v in g["growth_rate"]))
+        sd = make_state_dict(int(g["seed"]), args, calibrated=bool(g["calibrated"]))
+        out, keys = run_reference(ref_root, args, sd, g["left"], g["right"], torch.float32)
+        ok = keys == sorted(sd.keys()) and all(np.array_equal(out[i], g[f"pred{i}"]) for i in range(4))
+        print(f"{name}: {'OK' if ok else 'DIFFERS'} (226 structured names {'match' if keys == sorted(sd.keys()) else 'DIFFER'})")
+        bad += 0 if ok else 1
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--write", action="store_true")
+    ap.add_argument("--check-fixtures", nargs="+", metavar="NAME")
     a = ap.parse_args()
     torch.set_num_threads(min(8, os.cpu_count() or 1))
+    if a.check_fixtures:
+        return 1 if check_fixtures(a.reference, a.check_fixtures) else 0
     worst = 0.0
     for name, H, W, kind, kw, calib in CASES:
         args = default_args(**kw)

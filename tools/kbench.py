@@ -39,7 +39,8 @@ def main():
         m.set_option(k, int(v))
     B = a.batch
     rng = np.random.default_rng(0)
-    shapes = [(B, 16, H // 8, W // 8), (B, 16, H // 4, W // 4), (B, 8, H // 2, W // 2)]
+    H2, W2 = (H + 1) // 2, (W + 1) // 2          # the stem gives ceil(H/2); the hourglass halves twice more
+    shapes = [(B, 16, H2 // 4, W2 // 4), (B, 16, H2 // 2, W2 // 2), (B, 8, H2, W2)]
     fl = [torch.from_numpy(np.abs(rng.standard_normal(s)).astype(np.float32) * 0.5).to(dev) for s in shapes]
     fr = [torch.from_numpy(np.abs(rng.standard_normal(s)).astype(np.float32) * 0.5).to(dev) for s in shapes]
     for _ in range(5):
@@ -56,7 +57,7 @@ def main():
     _lib.check(lib.lws_profile_read(m._h, tot, cnt))
     _lib.check(lib.lws_profile_enable(m._h, 0))
     print(f"B={B} {H}x{W}: wall {wall * 1e6:.1f} us/iter (with event overhead), sum of kernels {sum(tot) / a.iters * 1e3:.1f} us")
-    vox = [B * 24 * (H // 8) * (W // 8), B * 9 * (H // 4) * (W // 4), B * 9 * (H // 2) * (W // 2)]
+    vox = [B * 24 * (H2 // 4) * (W2 // 4), B * 9 * (H2 // 2) * (W2 // 2), B * 9 * H2 * W2]
     for kc in range(_lib.LWS_KC_COUNT):
         if cnt[kc]:
             name = lib.lws_kernel_class_name(kc).decode()

@@ -8,10 +8,10 @@
 #include <stdio.h>
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-__global__ void k_sem(float *out)
+__global__ void k_sem(const float *ab, float *out)     // ab: [2][64] operands prepared on the host (no device rounding of them)
 {
     const int l = threadIdx.x;
-    const float a = 1.0f + 0.37f * (float)l, b = 2.0f - 0.011f * (float)l;
+    const float a = ab[l], b = ab[64 + l];
     floatx4 c0 = {0.5f, 0.25f, 0.125f, 1.0f}, c5 = c0, c15 = c0;
     c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 0, 0);
     c5 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c5, 4, 5, 0);
@@ -75,7 +75,14 @@ int main()
 {
     float *out, host[3 * 64 * 4];
     (void)hipMalloc(&out, 1 << 22);
-    k_sem<<<1, 64>>>(out);
+    float ab[128], *dab;
+    for (int l = 0; l < 64; ++l) {
+        ab[l] = 1.0f + 0.37f * (float)l + 1e-3f * (float)(l * l % 7);
+        ab[64 + l] = 2.0f - 0.011f * (float)l + 3e-4f * (float)(l % 5);
+    }
+    (void)hipMalloc(&dab, sizeof(ab));
+    (void)hipMemcpy(dab, ab, sizeof(ab), hipMemcpyHostToDevice);
+    k_sem<<<1, 64>>>(dab, out);
     (void)hipMemcpy(host, out, sizeof(host), hipMemcpyDeviceToHost);
     const int ids[3] = {0, 5, 15};
     const float cinit[4] = {0.5f, 0.25f, 0.125f, 1.0f};
@@ -83,9 +90,7 @@ int main()
     for (int t = 0; t < 3; ++t)
         for (int l = 0; l < 64; ++l)
             for (int i = 0; i < 4; ++i) {
-                const int src = 4 * ids[t] + i;
-                const float a = 1.0f + 0.37f * (float)src, b = 2.0f - 0.011f * (float)l;
-                const float want = fmaf(a, b, cinit[i]);
+                const float want = fmaf(ab[4 * ids[t] + i], ab[64 + l], cinit[i]);      // ONE rounding
                 if (host[(t * 64 + l) * 4 + i] != want) {
                     if (bad < 8) printf("MISMATCH abid=%d lane=%d reg=%d: got %.9g want %.9g\n", ids[t], l, i, host[(t * 64 + l) * 4 + i], want);
                     ++bad;
