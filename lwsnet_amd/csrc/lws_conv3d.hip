@@ -507,24 +507,29 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
     //      MFMAs below hold the vector issue port 8 cycles of every 10, so per-item VALU index math is paid in full:
     //      the per-item form of k_conv3d_mid8 cost ~35 VALU per 16 bytes here).  Rows are dealt round-robin to the waves;
     //      all loads of a wave are in flight before its first LDS write; out-of-volume voxels become literal zeros.
-    constexpr int NROW = Cfg::HD * HY, NW = Cfg::NW, RITER = (NROW + NW - 1) / NW, RI = 2 * HX;   // RI float4 per row
+    constexpr int NROW = Cfg::HD * HY, NW = Cfg::NW, RITER = NROW / NW, RI = 2 * HX;   // RI float4 per row
+    static_assert(NROW % NW == 0, "rows must deal out evenly to the waves");
     static_assert(RI > 64 && RI <= 128, "a row is two wave-loads");
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int j0 = lane, j1 = lane + 64;                    // the lane's two items of a row: voxel j >> 1, half j & 1
-    const int gx0 = x0 - 1 + (j0 >> 1), gx1 = x0 - 1 + (j1 >> 1);
-    const bool okx0 = gx0 >= 0 && gx0 < w, okx1 = j1 < RI && gx1 >= 0 && gx1 < w;
-    const int lo0 = (j0 & 1) * NP + (j0 >> 1), lo1 = (j1 & 1) * NP + (j1 >> 1);      // LDS slot inside the row
+    const int j1 = lane + 64;                               // the lane's items of a row: j = lane and lane + 64
+    const int gxa = x0 - 1 + (lane >> 1), gxb = x0 - 1 + (j1 >> 1);
+    const int oka = (gxa >= 0 && gxa < w) ? -1 : 0, okb = (j1 < RI && gxb >= 0 && gxb < w) ? -1 : 0;   // lane masks
     float4 c0[RITER], c1[RITER];
-    bool rok[RITER];
 #pragma unroll
     for (int k = 0; k < RITER; ++k) {
         const int row = wv + k * NW;                        // wave-uniform
         const int hd = row / HY, hy = row - hd * HY;
         const int gd = d0 + hd - 1, gy = y0 + hy - 1;
-        rok[k] = row < NROW && gd >= 0 && gd < D && gy >= 0 && gy < h;
-        const float *rb = inb + (rok[k] ? (((int64_t)gd * h + gy) * w + (x0 - 1)) * 8 : 0);      // (may point before the
-        c0[k] = *reinterpret_cast<const float4 *>((rok[k] && okx0) ? rb + 4 * j0 : inb);          //  row: guarded per lane)
-        c1[k] = *reinterpret_cast<const float4 *>((rok[k] && okx1) ? rb + 4 * j1 : inb);
+        const int rok = (gd >= 0 && gd < D && gy >= 0 && gy < h) ? -1 : 0;
+        // float offset of the row's first item (clamped rows read row (0, 0): always mapped); masked lanes read item 0
+        const int64_t ro = ((int64_t)(gd & rok) * h + (gy & rok)) * w * 8 + (int64_t)(x0 - 1) * 8;
+        const float *rb = inb + ro;
+        // (the row mask goes through a VGPR the compiler cannot see into: knowing it to be wave-uniform, hipcc branches
+        // around each row and parks the loaded rows in scratch)
+        int rokv = rok;
+        asm volatile("" : "+v"(rokv));
+        c0[k] = *reinterpret_cast<const float4 *>((rokv & oka) ? rb + 4 * lane : inb);
+        c1[k] = *reinterpret_cast<const float4 *>((rokv & okb) ? rb + 4 * j1 : inb);
     }
     // the 27 A registers of this lane ([tap / 4][lane][tap % 4]) and the next layer's BatchNorm (wave-uniform)
     float wa[28];
@@ -538,14 +543,19 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
     }
     const float4 s_lo = *reinterpret_cast<const float4 *>(bn_s), s_hi = *reinterpret_cast<const float4 *>(bn_s + 4);
     const float4 t_lo = *reinterpret_cast<const float4 *>(bn_t), t_hi = *reinterpret_cast<const float4 *>(bn_t + 4);
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int la = (lane & 1) * NP + (lane >> 1), lb = (j1 & 1) * NP + (j1 >> 1);      // LDS slot inside the row
 #pragma unroll
     for (int k = 0; k < RITER; ++k) {
         const int row = wv + k * NW;
-        if (row < NROW) {
-            lds4[row * HX + lo0] = (rok[k] && okx0) ? c0[k] : z4;
-            if (j1 < RI) lds4[row * HX + lo1] = (rok[k] && okx1) ? c1[k] : z4;
-        }
+        const int hd = row / HY, hy = row - hd * HY;
+        const int gd = d0 + hd - 1, gy = y0 + hy - 1;
+        int rokv = (gd >= 0 && gd < D && gy >= 0 && gy < h) ? -1 : 0;
+        asm volatile("" : "+v"(rokv));
+        // (component-wise selects: a select between two float4 OBJECTS is turned into a select of their addresses and
+        // drags both arrays into scratch)
+        const bool ma = (rokv & oka) != 0, mb = (rokv & okb) != 0;
+        lds4[row * HX + la] = make_float4(ma ? c0[k].x : 0.f, ma ? c0[k].y : 0.f, ma ? c0[k].z : 0.f, ma ? c0[k].w : 0.f);
+        if (j1 < RI) lds4[row * HX + lb] = make_float4(mb ? c1[k].x : 0.f, mb ? c1[k].y : 0.f, mb ? c1[k].z : 0.f, mb ? c1[k].w : 0.f);
     }
     __syncthreads();
     LWS_STAMPK(18, 1);
