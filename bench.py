@@ -28,6 +28,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin; two streams on one queue serialise.
+# A forward uses 3 streams (the caller's + 2 handle-owned side streams); PyTorch, RCCL (under torchrun) and the lws_pool
+# workers add theirs.  Measured r03 on one MI355X: under `torchrun --nproc-per-node 1` the default of 4 cost 12 % of every
+# step (0.563 vs 0.505 ms, with or without the gather) and the 4-worker pool 13 % (2,390 vs 2,740 pairs/s); 8 queues remove
+# both and leave the plain single-stream run unchanged (1,972 vs 1,975 pairs/s).  Read once, when HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
@@ -143,7 +149,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step (BASELINE config 2: 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the untimed lws_pool throughput extra")
-    ap.add_argument("--pool-workers", type=int, default=3, help="worker threads of the lws_pool extra")
+    ap.add_argument("--pool-workers", type=int, default=4, help="worker threads of the lws_pool extra")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent handles/HIP streams the steps rotate over (1 = every step on one stream; >1 "
                          "overlaps consecutive steps: higher pairs/s, but kernels then share CUs and their in-situ "
@@ -520,7 +526,7 @@ def main():
                                 if (H, W, args.maxdisp0) == (256, 512, 24) else
                                 f"batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[{args.maxdisp0},5,5], all 4 stages"),
                    "pairs_per_gpu": B, "streams": S, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4 per {G * B} pairs per rank" if grouped else "single GPU",
-                   "weights": "seeded synthetic (seed 7, calibrated BN)", **({"options": args.opt} if args.opt else {})},
+                   "weights": "seeded synthetic (seed 7, calibrated BN)", "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), **({"options": args.opt} if args.opt else {})},
         "roofline": _with_traffic(roof, B), "secondary": secondary, "cpu_baseline": cpu, "latency_ms": latency, "pipelined": pipelined,
         "hbm_kernels": hbm,
         "hot_path_kernel_ms_per_step": round(hot_ms, 4), "all_kernel_ms_per_step": round(all_ms, 4), "kernels": {k: {a: round(b, 2) for a, b in v.items()} for k, v in kernels.items()},

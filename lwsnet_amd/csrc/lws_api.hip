@@ -763,7 +763,10 @@ int lws_create(const lws_config *cfg, lws_handle *out)
 // copies the per-handle options into the per-layer structs the launchers read
 static void apply_options(lws_ctx *h)
 {
-    for (int i = 0; i < 3; ++i) h->stage[i].mid8_form = h->opt.mid8_form;
+    for (int i = 0; i < 3; ++i) {
+        h->stage[i].mid8_form = h->opt.mid8_form;
+        h->stage[i].dfast = h->opt.conv3d_order;
+    }
     lws::Net2d &n = h->net2d;
     for (int k = 0; k < 2; ++k)
         for (int b = 0; b < 4; ++b) n.r1[k][b].order = h->opt.ref_order;
@@ -780,6 +783,7 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"defer_upsample", &h->opt.defer_upsample},
                                                      {"side_streams", &h->opt.side_streams},
                                                      {"ref_order", &h->opt.ref_order},
+                                                     {"conv3d_order", &h->opt.conv3d_order},
                                                      {"device", &h->device},
                                                      {"mid8_form", &h->opt.mid8_form}};
     for (auto &e : tab)

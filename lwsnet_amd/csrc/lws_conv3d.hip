@@ -30,6 +30,25 @@ LWS_DEFINE_STAMPS(conv3d)
 
 __device__ __forceinline__ float bn_relu(float x, float s, float t) { return fmaxf(fmaf(x, s, t), 0.0f); }
 
+// tile index (already XCD-contiguous, xcd_tile) -> tile coordinates.  dfast == 0: x fastest, then y, then d.  dfast != 0: d
+// fastest, then x, then y -- the tiles that share halo planes along d (2 of the 5 planes a 3-deep tile reads) and along y
+// are then neighbours in an XCD's run and co-resident, so their re-reads hit that XCD's L2 instead of the fabric.
+// The same map in every layer of a stack: a consumer tile finds its producer's output in the same L2.  Speed only.
+__device__ __forceinline__ void tile_coords(int tile, int tiles_x, int tiles_y, int tiles_d, int dfast, int &tx, int &ty, int &td)
+{
+    if (dfast) {
+        td = tile % tiles_d;
+        tile /= tiles_d;
+        tx = tile % tiles_x;
+        ty = tile / tiles_x;
+    } else {
+        tx = tile % tiles_x;
+        tile /= tiles_x;
+        ty = tile % tiles_y;
+        td = tile / tiles_y;
+    }
+}
+
 // compile-time component select (j is always a constant after unrolling)
 __device__ __forceinline__ float f4(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
@@ -82,7 +101,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
                                                               const float *__restrict__ bn_s,   // next layer BN [C3]
                                                               const float *__restrict__ bn_t,
                                                               float *__restrict__ out, int D, int h, int w,
-                                                              int tiles_x, int tiles_y, int wt)
+                                                              int tiles_x, int tiles_y, int wt, int tord)
 {
     using Cfg = Mid16Cfg<C3, TD, TY, WR, WM>;
     constexpr int MT = Cfg::MT, Q = Cfg::Q, RW = Cfg::RW, MTW = Cfg::MTW, HY = Cfg::HY, HX = Cfg::HX, VS = Cfg::VS;
@@ -92,11 +111,8 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WM, wm = wave % WM;     // this wave's row group / output-channel group
     const int n = lane & 15, g = lane >> 4;
-    int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int tx = tile % tiles_x;
-    tile /= tiles_x;
-    const int ty = tile % tiles_y;
-    const int td = tile / tiles_y;
+    int tx, ty, td;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
     const int b = blockIdx.y;
     const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * C3;
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
                                                      const float *__restrict__ bn_s,    // next layer BN [8]
                                                      const float *__restrict__ bn_t,
                                                      float *__restrict__ out, int D, int h, int w,
-                                                     int tiles_x, int tiles_y, int wt)
+                                                     int tiles_x, int tiles_y, int wt, int tord)
 {
     using Cfg = Mid8Cfg<TD, TY>;
     constexpr int RW = Cfg::RW, HY = Cfg::HY, HX = Cfg::HX, PS = Cfg::PS;
@@ -328,11 +344,8 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    int tile = xcd_tile(blockIdx.x, gridDim.x);   // same XCD-contiguous tile map in every layer of the stack
-    const int tx = tile % tiles_x;
-    tile /= tiles_x;
-    const int ty = tile % tiles_y;
-    const int td = tile / tiles_y;
+    int tx, ty, td;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
     const int b = blockIdx.y;
     const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * 8;
@@ -483,7 +496,7 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
                                                                         const float *__restrict__ bn_s,    // next layer BN [8]
                                                                         const float *__restrict__ bn_t,
                                                                         float *__restrict__ out, int D, int h, int w,
-                                                                        int tiles_x, int tiles_y, int wt)
+                                                                        int tiles_x, int tiles_y, int wt, int tord)
 {
     using Cfg = Mid8qCfg<TD, TY>;
     constexpr int HY = Cfg::HY, HX = Cfg::HX, NP = Cfg::NP;
@@ -491,46 +504,39 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
     float4 *lds4 = reinterpret_cast<float4 *>(lds);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int tx = tile % tiles_x;
-    tile /= tiles_x;
-    const int ty = tile % tiles_y;
-    const int td = tile / tiles_y;
+    int tx, ty, td;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
     const int b = blockIdx.y;
     const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * 8;
     LWS_STAMPK(18, 0);
 
-    // ---- stage, one halo ROW per wave-instruction: a row of the halo tile is HX voxels x 8 channels = 2 HX contiguous
-    //      float4 in global memory, so lane j of item group (row, j) loads base_row + 16 j bytes and everything about the
-    //      row -- its (d, y), its validity, its global base, its LDS offset -- is wave-uniform (SGPR arithmetic; the
-    //      MFMAs below hold the vector issue port 8 cycles of every 10, so per-item VALU index math is paid in full:
-    //      the per-item form of k_conv3d_mid8 cost ~35 VALU per 16 bytes here).  Rows are dealt round-robin to the waves;
-    //      all loads of a wave are in flight before its first LDS write; out-of-volume voxels become literal zeros.
-    constexpr int NROW = Cfg::HD * HY, NW = Cfg::NW, RITER = NROW / NW, RI = 2 * HX;   // RI float4 per row
-    static_assert(NROW % NW == 0, "rows must deal out evenly to the waves");
-    static_assert(RI > 64 && RI <= 128, "a row is two wave-loads");
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int j1 = lane + 64;                               // the lane's items of a row: j = lane and lane + 64
-    const int gxa = x0 - 1 + (lane >> 1), gxb = x0 - 1 + (j1 >> 1);
-    const int oka = (gxa >= 0 && gxa < w) ? -1 : 0, okb = (j1 < RI && gxb >= 0 && gxb < w) ? -1 : 0;   // lane masks
-    float4 c0[RITER], c1[RITER];
+    // ---- stage: item = (voxel, channel half) = 16 B, enumerated plane by plane; all global loads of a thread are in
+    //      flight before its first LDS write; out-of-volume voxels become literal zeros (the convolution's padding).
+    //      Two phases as in k_conv3d_mid16: iterations i < P1 cover halo planes [0, TD) -- all the kd = 0 taps read, for
+    //      every wave -- and are written first; the rest lands in LDS after the kd = 0 taps, under their MFMAs.
+    //      (Measured r03: a row-per-wave-instruction form with wave-uniform row arithmetic, 134 instead of 273 VALU
+    //      instructions in front of the first MFMA, was SLOWER -- 105.8 vs 95.8 us at 8 x 9x128x256: a 34-voxel row is
+    //      68 float4, i.e. a second, 4-lane load per row, 60 instead of 36 wave-loads per tile, and the staging is bound
+    //      by the CU's fetch path (~10 B/cycle/CU from beyond L2), not by index arithmetic.)
+    constexpr int NT = Cfg::NT, SITER = Cfg::SITER;
+    constexpr int P1 = (TD * HY * HX * 2 + NT - 1) / NT < SITER ? (TD * HY * HX * 2 + NT - 1) / NT : SITER;
+    float4 c[SITER];
+    bool okv[SITER];
 #pragma unroll
-    for (int k = 0; k < RITER; ++k) {
-        const int row = wv + k * NW;                        // wave-uniform
-        const int hd = row / HY, hy = row - hd * HY;
-        const int gd = d0 + hd - 1, gy = y0 + hy - 1;
-        const int rok = (gd >= 0 && gd < D && gy >= 0 && gy < h) ? -1 : 0;
-        // float offset of the row's first item (clamped rows read row (0, 0): always mapped); masked lanes read item 0
-        const int64_t ro = ((int64_t)(gd & rok) * h + (gy & rok)) * w * 8 + (int64_t)(x0 - 1) * 8;
-        const float *rb = inb + ro;
-        // (the row mask goes through a VGPR the compiler cannot see into: knowing it to be wave-uniform, hipcc branches
-        // around each row and parks the loaded rows in scratch)
-        int rokv = rok;
-        asm volatile("" : "+v"(rokv));
-        c0[k] = *reinterpret_cast<const float4 *>((rokv & oka) ? rb + 4 * lane : inb);
-        c1[k] = *reinterpret_cast<const float4 *>((rokv & okb) ? rb + 4 * j1 : inb);
+    for (int i = 0; i < SITER; ++i) {
+        const int it = tid + i * NT;
+        const int half = it & 1, v = it >> 1;
+        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        okv[i] = it < Cfg::ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        c[i] = *reinterpret_cast<const float4 *>(inb + (okv[i] ? (((int64_t)gd * h + gy) * w + gx) * 8 + half * 4 : 0));
     }
+    auto stage_write = [&](int i) {
+        const int it = tid + i * NT;
+        if (it < Cfg::ITEMS)
+            lds4[(it & 1) * NP + (it >> 1)] = make_float4(okv[i] ? c[i].x : 0.f, okv[i] ? c[i].y : 0.f, okv[i] ? c[i].z : 0.f, okv[i] ? c[i].w : 0.f);
+    };
     // the 27 A registers of this lane ([tap / 4][lane][tap % 4]) and the next layer's BatchNorm (wave-uniform)
     float wa[28];
 #pragma unroll
@@ -543,20 +549,8 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
     }
     const float4 s_lo = *reinterpret_cast<const float4 *>(bn_s), s_hi = *reinterpret_cast<const float4 *>(bn_s + 4);
     const float4 t_lo = *reinterpret_cast<const float4 *>(bn_t), t_hi = *reinterpret_cast<const float4 *>(bn_t + 4);
-    const int la = (lane & 1) * NP + (lane >> 1), lb = (j1 & 1) * NP + (j1 >> 1);      // LDS slot inside the row
 #pragma unroll
-    for (int k = 0; k < RITER; ++k) {
-        const int row = wv + k * NW;
-        const int hd = row / HY, hy = row - hd * HY;
-        const int gd = d0 + hd - 1, gy = y0 + hy - 1;
-        int rokv = (gd >= 0 && gd < D && gy >= 0 && gy < h) ? -1 : 0;
-        asm volatile("" : "+v"(rokv));
-        // (component-wise selects: a select between two float4 OBJECTS is turned into a select of their addresses and
-        // drags both arrays into scratch)
-        const bool ma = (rokv & oka) != 0, mb = (rokv & okb) != 0;
-        lds4[row * HX + la] = make_float4(ma ? c0[k].x : 0.f, ma ? c0[k].y : 0.f, ma ? c0[k].z : 0.f, ma ? c0[k].w : 0.f);
-        if (j1 < RI) lds4[row * HX + lb] = make_float4(mb ? c1[k].x : 0.f, mb ? c1[k].y : 0.f, mb ? c1[k].z : 0.f, mb ? c1[k].w : 0.f);
-    }
+    for (int i = 0; i < P1; ++i) stage_write(i);
     __syncthreads();
     LWS_STAMPK(18, 1);
 
@@ -566,7 +560,12 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
     const float4 *bp = lds4 + (pd * HY + ly) * HX + lx;
     floatx4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kd = 0; kd < 3; ++kd)
+    for (int kd = 0; kd < 3; ++kd) {
+        if (kd == 1 && P1 < SITER) {
+#pragma unroll
+            for (int i = P1; i < SITER; ++i) stage_write(i);
+            __syncthreads();
+        }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -583,6 +582,7 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
                 LWS_Q2(6, b1.z)
                 LWS_Q2(7, b1.w)
             }
+    }
     LWS_STAMPK(18, 2);
 
     // ---- epilogue: register i of lo / hi = output channel i / 4 + i of this lane's voxel; next layer's BN + ReLU;
@@ -619,18 +619,15 @@ __global__ __launch_bounds__(256) void k_conv3d_first8(const float *__restrict__
                                                        const float *__restrict__ bn0_s, const float *__restrict__ bn0_t,
                                                        const float *__restrict__ bn_s,    // next layer BN [8]
                                                        const float *__restrict__ bn_t, float *__restrict__ out, int D,
-                                                       int h, int w, int tiles_x, int tiles_y)
+                                                       int h, int w, int tiles_x, int tiles_y, int tord)
 {
     constexpr int RW = TD * TY / 4, HD = TD + 2, HY = TY + 2, HX = 34, NVOX = HD * HY * HX, SITER = (NVOX + 255) / 256;
     static_assert(TD * TY % 4 == 0, "rows must split over 4 waves");
     __shared__ float lds[NVOX];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int tx = tile % tiles_x;
-    tile /= tiles_x;
-    const int ty = tile % tiles_y;
-    const int td = tile / tiles_y;
+    int tx, ty, td;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
     const int b = blockIdx.y;
     const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
     const float *cb = cost + (int64_t)b * D * h * w;
@@ -708,7 +705,7 @@ __global__ __launch_bounds__(256) void k_conv3d_first16(float *__restrict__ cost
                                                         const float *__restrict__ bn0_s, const float *__restrict__ bn0_t,
                                                         const float *__restrict__ bn_s,    // next layer BN [C3]
                                                         const float *__restrict__ bn_t, float *__restrict__ out, int D,
-                                                        int h, int w, int tiles_x, int tiles_y)
+                                                        int h, int w, int tiles_x, int tiles_y, int tord)
 {
     constexpr int MT = C3 / 16, RW = TD * TY / 4, HD = TD + 2, HY = TY + 2, HX = 18, NVOX = HD * HY * HX,
                   SITER = (NVOX + 255) / 256;
@@ -716,11 +713,8 @@ __global__ __launch_bounds__(256) void k_conv3d_first16(float *__restrict__ cost
     __shared__ float lds[NVOX];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int tx = tile % tiles_x;
-    tile /= tiles_x;
-    const int ty = tile % tiles_y;
-    const int td = tile / tiles_y;
+    int tx, ty, td;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
     const int b = blockIdx.y;
     const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
     float *cb = cost + (int64_t)b * D * h * w;
@@ -888,17 +882,14 @@ template <int C3, int TD, int TY, int TX, bool FUSE>
 __global__ __launch_bounds__((LastCfg<C3, TD, TY, TX, FUSE>::NT)) void k_conv3d_last(
     const float *__restrict__ act, const float *__restrict__ wgt,   // [27][C3]
     const float *__restrict__ skip, float *__restrict__ cost_out,  // may be nullptr when FUSE
-    float *__restrict__ low, float start, int D, int h, int w, int tiles_x, int tiles_y)
+    float *__restrict__ low, float start, int D, int h, int w, int tiles_x, int tiles_y, int tord)
 {
     using Cfg = LastCfg<C3, TD, TY, TX, FUSE>;
     constexpr int HY = Cfg::HY, HX = Cfg::HX, VS = Cfg::VS, NT = Cfg::NT, SITER = Cfg::SITER, C4 = C3 / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int tx_ = tile % tiles_x;
-    tile /= tiles_x;
-    const int ty_ = tile % tiles_y;
-    const int td_ = tile / tiles_y;
+    int tx_, ty_, td_;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx_, ty_, td_);
     const int b = blockIdx.y;
     const int x0 = tx_ * TX, y0 = ty_ * TY, d0 = td_ * TD;
     const int64_t vol = (int64_t)D * h * w;
@@ -1030,7 +1021,7 @@ int launch_shift_first(const Stage3d &s, const float *L, const float *R, float *
 #define LWS_SF(C3v, SH)                                                                                               \
     hipLaunchKernelGGL((k_conv3d_first16<C3v, TD, TY, SH>), grid, block, 0, st, cost, L, R, s.layers[0].w_mfma,        \
                        s.layers[0].bn_s, s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w,      \
-                       tiles_x, tiles_y)
+                       tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0))
     if (s.c3 == 32) {
         if (q16) LWS_SF(32, 2);
         else LWS_SF(32, 1);
@@ -1051,7 +1042,8 @@ int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int
         const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
         dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
         hipLaunchKernelGGL((k_conv3d_first8<TD, TY>), grid, block, 0, st, cost, s.layers[0].w_mfma, s.layers[0].bn_s,
-                           s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w, tiles_x, tiles_y);
+                           s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w, tiles_x, tiles_y,
+                           2 * tiles_d + (s.dfast ? 1 : 0));
         LWS_LAUNCH_CHECK();
         return LWS_OK;
     }
@@ -1064,11 +1056,11 @@ int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int
         if (s.c3 == 32)
             hipLaunchKernelGGL((k_conv3d_first16<32, TD, TY, 0>), grid, block, 0, st, cin, nofeat, nofeat, s.layers[0].w_mfma,
                                s.layers[0].bn_s, s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w,
-                               tiles_x, tiles_y);
+                               tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
         else
             hipLaunchKernelGGL((k_conv3d_first16<16, TD, TY, 0>), grid, block, 0, st, cin, nofeat, nofeat, s.layers[0].w_mfma,
                                s.layers[0].bn_s, s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w,
-                               tiles_x, tiles_y);
+                               tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
         LWS_LAUNCH_CHECK();
         return LWS_OK;
     }
@@ -1096,11 +1088,11 @@ static int mid16_launch(const Stage3d &s, int layer, const float *in, float *out
         // profiler on: the events carry the kernel's own begin / end timestamps (no dispatch latency in between)
         hipExtLaunchKernelGGL((k_conv3d_mid16<C3, TD, TY, WR, WM>), grid, block, Cfg::LDS_BYTES, st, e0, e1, 0, in,
                               reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
-                              s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt);
+                              s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt, 2 * tiles_d + (s.dfast ? 1 : 0));
     } else {
         hipLaunchKernelGGL((k_conv3d_mid16<C3, TD, TY, WR, WM>), grid, block, Cfg::LDS_BYTES, st, in,
                            reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
-                           s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt);
+                           s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt, 2 * tiles_d + (s.dfast ? 1 : 0));
     }
     LWS_LAUNCH_CHECK();
     return LWS_OK;
@@ -1119,7 +1111,8 @@ static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out,
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
     hipLaunchKernelGGL((k_conv3d_mid8<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w,
-                       s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, /*wt=*/0);
+                       s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, /*wt=*/0,
+                       2 * tiles_d + (s.dfast ? 1 : 0));
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -1136,7 +1129,8 @@ static int mid8q_launch(const Stage3d &s, int layer, const float *in, float *out
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
     hipLaunchKernelGGL((k_conv3d_mid8q<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w + MID8_PACK,
-                       s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, /*wt=*/0);
+                       s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, /*wt=*/0,
+                       2 * tiles_d + (s.dfast ? 1 : 0));
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -1174,7 +1168,7 @@ static int last_launch(const Stage3d &s, const float *act, const float *skip, fl
     const int tiles_x = cdiv(w, TX), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
     hipLaunchKernelGGL((k_conv3d_last<C3, TD, TY, TX, FUSE>), grid, block, Cfg::LDS_BYTES, st, act, s.layers.back().w,
-                       skip, cost_out, low, start, D, h, w, tiles_x, tiles_y);
+                       skip, cost_out, low, start, D, h, w, tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }

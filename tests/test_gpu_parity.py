@@ -274,7 +274,8 @@ def test_forward_repeatable_batch8(dev, model):
 
 
 OPTION_PLANS = [{"left_at": 0}, {"left_at": 2}, {"split_heads": 1}, {"split_heads": 0}, {"fuse_shift": 0},
-                {"fuse_first": 0}, {"defer_upsample": 0}, {"mid8_form": 1}, {"ref_order": 1}, {"ref_order": 2},
+                {"fuse_first": 0}, {"defer_upsample": 0}, {"mid8_form": 1}, {"mid8_form": 0}, {"ref_order": 1}, {"ref_order": 2},
+                {"conv3d_order": 1}, {"conv3d_order": 0},
                 {"side_streams": 0}, {"side_streams": 0, "left_at": 0}, {"left_at": 2, "split_heads": 1},
                 {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0, "mid8_form": 1}]
 

@@ -10,11 +10,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--size", default="256x512")
 ap.add_argument("--iters", type=int, default=40)
+ap.add_argument("--opt", action="append", default=[])
 a = ap.parse_args()
 H, W = [int(v) for v in a.size.split("x")]
 dev = torch.device("cuda:0")
 m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
 lib = _lib.load()
+for o in a.opt:
+    m.set_option(o.split('=')[0], int(o.split('=')[1]))
 for stage, (D, div) in ((1, (9, 4)), (2, (9, 2))):
     c = torch.rand((a.batch, D, H // div, W // div), device=dev) * 12
     for form in (0, 1):
@@ -33,4 +36,4 @@ for stage, (D, div) in ((1, (9, 4)), (2, (9, 2))):
         kc = 4
         avg = tot[kc] / cnt[kc] * 1e3
         gf = 2 * 27 * 8 * 8 * a.batch * D * (H // div) * (W // div)
-        print(f"stage {stage + 1} B={a.batch} mid8_form={form}: k_conv3d_mid8 avg {avg:7.2f} us = {gf / avg / 1e6:6.1f} TF useful")
+        print(f"stage {stage + 1} B={a.batch} {" ".join(a.opt)} mid8_form={form}: k_conv3d_mid8 avg {avg:7.2f} us = {gf / avg / 1e6:6.1f} TF useful")
