@@ -515,10 +515,38 @@ static int feature_tail(lws_ctx *h, int N, int H, int W, const WsLayout &L, floa
     if (rc) return rc;
 
 // refinement1_left(left) (models.py:158): depends on the left image only -> result in r_a (r_c is its scratch)
+// The refinement maps are [B,H,W,32] float32 = 128 B per pixel (134 MB at 8 x 256x512) and every block reads one and writes
+// another.  A chunk of pairs runs its whole layer chain before the next chunk starts, sized so that one map of the chunk is
+// at most `ref_chunk_mb` MB: the three maps a block chain touches then stay in the 256 MiB Infinity Cache between a block's
+// write and the next block's read (MI355X_MICROARCH.md: a table stays resident while it plus everything moved between two
+// uses fits in ~256 MiB).  Measured r03 (tools/rbench.py, per pair): k_ref_dws 8.25 us at batch 8 against 7.5 us at batch 4.
+// 0 = one chunk.  Pairs are independent, so chunking cannot change a bit.
+static int refine_chunk(const lws_ctx *h, int B, int H, int W)
+{
+    if (h->opt.ref_chunk_mb <= 0) return B;
+    const double map_mb = (double)H * W * 128.0 / 1e6;
+    int c = (int)((double)h->opt.ref_chunk_mb / map_mb);
+    c = c < 1 ? 1 : c;
+    return c < B ? c : B;
+}
+
+static int refine_left_chunk(lws_ctx *h, const float *left, int B, int H, int W, const WsLayout &L, hipStream_t st, int b0);
+
 static int refine_left(lws_ctx *h, const float *left, int B, int H, int W, const WsLayout &L, hipStream_t st)
 {
+    const int CH = refine_chunk(h, B, H, W);
+    for (int b0 = 0; b0 < B; b0 += CH) {
+        const int rc = refine_left_chunk(h, left + (size_t)b0 * 3 * H * W, std::min(CH, B - b0), H, W, L, st, b0);
+        if (rc) return rc;
+    }
+    return LWS_OK;
+}
+
+static int refine_left_chunk(lws_ctx *h, const float *left, int B, int H, int W, const WsLayout &L, hipStream_t st, int b0)
+{
     const Net2d &n = h->net2d;
-    float *ra = h->ws + L.r_a, *rc_ = h->ws + L.r_c;
+    // the result keeps its slice of r_a; the scratch map r_c is the SAME memory for every chunk (it stays cache-resident)
+    float *ra = h->ws + L.r_a + (size_t)b0 * H * W * 32, *rc_ = h->ws + L.r_c;
     int rc;
     LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(left, 3, n.r1_first[0], ra, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][0], ra, rc_, B, H, W, st));
@@ -543,11 +571,28 @@ struct DeferState {
 
 static bool refine_can_defer(const lws_ctx *h);
 
+static int refine_rest_chunk(lws_ctx *h, float *pred3, int B, int H, int W, const WsLayout &L, float *pred4, hipStream_t st,
+                             const DeferState *ds, const float *pred2, int b0);
+
 static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLayout &L, float *pred4,
                        hipStream_t st, const DeferState *ds = nullptr, const float *pred2 = nullptr)
 {
+    const int CH = (ds != nullptr && ds->def[2]) ? B : refine_chunk(h, B, H, W);      // (deferred maps: batches <= 2, one chunk)
+    for (int b0 = 0; b0 < B; b0 += CH) {
+        const size_t po = (size_t)b0 * H * W;
+        const int rc = refine_rest_chunk(h, pred3 + po, std::min(CH, B - b0), H, W, L, pred4 + po, st, ds,
+                                         pred2 != nullptr ? pred2 + po : nullptr, b0);
+        if (rc) return rc;
+    }
+    return LWS_OK;
+}
+
+static int refine_rest_chunk(lws_ctx *h, float *pred3, int B, int H, int W, const WsLayout &L, float *pred4, hipStream_t st,
+                             const DeferState *ds, const float *pred2, int b0)
+{
     const Net2d &n = h->net2d;
-    float *ra = h->ws + L.r_a, *rb = h->ws + L.r_b, *rc_ = h->ws + L.r_c;
+    // r_a: this chunk's slice (refinement1_left's result); r_b, r_c: the same memory for every chunk
+    float *ra = h->ws + L.r_a + (size_t)b0 * H * W * 32, *rb = h->ws + L.r_b, *rc_ = h->ws + L.r_c;
     int rc;
     if (h->opt.fuse_first && ref_first_dws_can_fuse(n.r1[1][0], 1)) {
         // refinement1_disp: the 1 -> 32 convolution is recomputed inside the first block's staging (one launch less)
@@ -784,6 +829,7 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"side_streams", &h->opt.side_streams},
                                                      {"ref_order", &h->opt.ref_order},
                                                      {"conv3d_order", &h->opt.conv3d_order},
+                                                     {"ref_chunk_mb", &h->opt.ref_chunk_mb},
                                                      {"device", &h->device},
                                                      {"mid8_form", &h->opt.mid8_form}};
     for (auto &e : tab)
@@ -800,6 +846,8 @@ int lws_set_option(lws_handle h, const char *name, int value)
         LWS_CHECK_ARG(value == -1 || value == 0 || value == 2, "lws_set_option: left_at must be -1 (auto), 0 or 2 (got %d)", value);
     else if (strcmp(name, "split_heads") == 0)
         LWS_CHECK_ARG(value >= -1 && value <= 1, "lws_set_option: split_heads must be -1 (auto), 0 or 1 (got %d)", value);
+    else if (strcmp(name, "ref_chunk_mb") == 0)
+        LWS_CHECK_ARG(value >= 0 && value <= 4096, "lws_set_option: ref_chunk_mb must be in 0..4096 (got %d)", value);
     else if (strcmp(name, "ref_order") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 2, "lws_set_option: ref_order must be 0, 1 or 2 (got %d)", value);
     else if (strcmp(name, "device") == 0) {

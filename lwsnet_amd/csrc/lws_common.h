@@ -167,6 +167,7 @@ struct lws_ctx {
         int mid8_form = 0;         // 8 -> 8 Conv3D layers: 0 = k_conv3d_mid8 (16x16x4), 1 = k_conv3d_mid8q (4x4x1_16B, no zero padding)
         int side_streams = 1;      // 0: no handle-owned side streams, the whole forward on the caller's stream (lws_pool workers)
         int conv3d_order = 0;      // tile order of the Conv3D stacks: 0 = x fastest, 1 = d fastest (halo planes shared inside an XCD's L2)
+        int ref_chunk_mb = 0;      // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
         int ref_order = 0;         // block -> tile order of the phase-grid refinement kernels (0 = dispatch order, 1/2 = XCD-contiguous)
     } opt;
     unsigned prof_mask = 0;                  // kernel classes being timed in the current call

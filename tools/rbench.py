@@ -46,6 +46,15 @@ def main():
         tot = (ctypes.c_double * _lib.LWS_KC_COUNT)()
         cnt = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
         _lib.check(lib.lws_profile_read(m._h, tot, cnt))
+        each = (ctypes.c_float * 8192)()
+        n_each = ctypes.c_int(0)
+        _lib.check(lib.lws_profile_read_class(m._h, 10, each, 8192, ctypes.byref(n_each)))      # LWS_KC_REF_DWS
+        per = n_each.value // a.iters
+        if per:
+            # launch order inside lws_refine: refinement1_left d = 2,4,8,16; refinement1_disp 2 (+ first conv),4,8,16; refinement2 8,4,2,1
+            dil = [2, 4, 8, 16, 2, 4, 8, 16, 8, 4, 2, 1][:per]
+            avg = [sum(each[k * per + j] for k in range(a.iters)) / a.iters * 1e3 for j in range(per)]
+            print("   ref_dws per launch (dilation: us): " + "  ".join(f"d{d}:{u:.1f}" for d, u in zip(dil, avg)))
         _lib.check(lib.lws_profile_enable(m._h, 0))
         print(f"ref_order={fuse} B={a.batch} {H}x{W}: wall {wall * 1e6:.1f} us per lws_refine; kernels (with event overhead):")
         for kc in range(_lib.LWS_KC_COUNT):

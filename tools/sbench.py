@@ -16,6 +16,7 @@ H, W = [int(v) for v in a.size.split("x")]
 dev = torch.device("cuda:0")
 m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
 lib = _lib.load()
+opts = ' '.join(a.opt)
 for o in a.opt:
     m.set_option(o.split('=')[0], int(o.split('=')[1]))
 for stage, (D, div) in ((1, (9, 4)), (2, (9, 2))):
@@ -36,4 +37,4 @@ for stage, (D, div) in ((1, (9, 4)), (2, (9, 2))):
         kc = 4
         avg = tot[kc] / cnt[kc] * 1e3
         gf = 2 * 27 * 8 * 8 * a.batch * D * (H // div) * (W // div)
-        print(f"stage {stage + 1} B={a.batch} {" ".join(a.opt)} mid8_form={form}: k_conv3d_mid8 avg {avg:7.2f} us = {gf / avg / 1e6:6.1f} TF useful")
+        print(f"stage {stage + 1} B={a.batch} {opts} mid8_form={form}: k_conv3d_mid8 avg {avg:7.2f} us = {gf / avg / 1e6:6.1f} TF useful")
