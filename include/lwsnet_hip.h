@@ -136,13 +136,19 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "fuse_shift"     1 (default) = stage-1 volume built inside the first Conv3D launch
  *   "fuse_first"     1 (default) = refinement1_disp's 1 -> 32 convolution inside its first depthwise block
  *   "defer_upsample" 1 (default) = at batches <= 2 the consumers evaluate the stage-2/3 maps
- *   "mid8_form"      the 8 -> 8 Conv3D layers (stages 2, 3): 0 = v_mfma_f32_16x16x4_f32 with rows = (x parity, cout)
- *                    (k_conv3d_mid8: 25 % of every instruction is structural zero padding), 1 = v_mfma_f32_4x4x1_16B_f32
- *                    with the A block broadcast (k_conv3d_mid8q: 4 couts x 64 voxels per instruction, no padding)
+ *   "mid8_form"      the 8 -> 8 Conv3D layers (stages 2, 3): 1 (default) = v_mfma_f32_4x4x1_16B_f32 with the A block
+ *                    broadcast (k_conv3d_mid8q: 4 couts x 64 voxels per instruction, no padding), 0 = v_mfma_f32_16x16x4_f32
+ *                    with rows = (x parity, cout) (k_conv3d_mid8: 25 % of every instruction is structural zero padding;
+ *                    measured r03 8-17 % slower)
+ *   "conv3d_order"   tile order of the Conv3D kernels inside an XCD's run: 1 (default) = d fastest (the tiles that share
+ *                    halo planes are co-resident: re-reads hit that XCD's L2), 0 = x fastest
  *   "side_streams"   1 (default) = refinement1_left and the feature-extractor tail run on handle-owned side streams;
  *                    0 = the whole forward on the caller's stream, no forks / joins (what lws_pool workers use)
- *   "ref_order"      block -> tile order of the phase-grid refinement kernels: 0 = dispatch order, 1 = XCD-contiguous,
- *                    2 = XCD-contiguous with the dilation phase slowest
+ *   "ref_chunk_mb"   72 (default): the refinement runs in chunks of pairs whose [b,H,W,32] maps are at most this many MB
+ *                    each, so that a chunk's maps stay in the 256 MiB Infinity Cache between layers (batch 8 at 256x512:
+ *                    two chunks of 4; 368x1232: one pair per chunk); 0 = one chunk
+ *   "ref_order"      block -> tile order of the phase-grid refinement kernels: 0 (default) = dispatch order,
+ *                    1 = XCD-contiguous, 2 = XCD-contiguous with the dilation phase slowest (measured r03: no gain)
  *   "device"         the HIP device the handle belongs to; settable only before lws_finalize / lws_reserve allocate
  * Unknown names and out-of-range values return LWS_ERR_INVALID. */
 int lws_set_option(lws_handle h, const char *name, int value);

@@ -1143,6 +1143,10 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
         case 8: {
             // (whole-D tiles, 9 rows per wave, measured r01: 19.3 vs 17.0 us at B=1 256x512 -- one wave per SIMD cannot
             // overlap its own staging with its MFMAs, three co-resident small workgroups can)
+            // Measured r03 (tools/sbench.py, one run, us per launch, 16x16x4 parity-row tiles vs 4x4x1_16B): stage 2 (9 x 64 x 128)
+            // 8.7 vs 7.8 at B = 1, 13.4 vs 12.2 at B = 2, 32.5 vs 29.0 at B = 8; stage 3 (9 x 128 x 256) 17.6 vs 15.9, 30.0 vs 28.8,
+            // 105.0 vs 94.8; 8 x 368x1232: 102 vs 85 and 369 vs 328.  (Without the two-phase staging the 4x4x1 form lost at
+            // 8 x 9x64x128 and 2 x 9x128x256: 34.5 and 33.3 us.)
             if (s.mid8_form == 1) return mid8q_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
             return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
         }

@@ -108,7 +108,7 @@ def test_conv3d_stack_bitexact(dev, model, stage, shape):
         try:
             got = ops.conv3d_stack(model._h, stage, cu(c, dev))
         finally:
-            model.set_option("mid8_form", 0)
+            model.set_option("mid8_form", 1)
         assert_bits(got, want, f"conv3d_stack stage {stage} {shape} mid8_form={form}")
 
 
@@ -275,7 +275,7 @@ def test_forward_repeatable_batch8(dev, model):
 
 OPTION_PLANS = [{"left_at": 0}, {"left_at": 2}, {"split_heads": 1}, {"split_heads": 0}, {"fuse_shift": 0},
                 {"fuse_first": 0}, {"defer_upsample": 0}, {"mid8_form": 1}, {"mid8_form": 0}, {"ref_order": 1}, {"ref_order": 2},
-                {"conv3d_order": 1}, {"conv3d_order": 0},
+                {"conv3d_order": 1}, {"conv3d_order": 0}, {"ref_chunk_mb": 0}, {"ref_chunk_mb": 1},
                 {"side_streams": 0}, {"side_streams": 0, "left_at": 0}, {"left_at": 2, "split_heads": 1},
                 {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0, "mid8_form": 1}]
 

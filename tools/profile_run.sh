@@ -31,3 +31,16 @@ python tools/sbench.py > "$O/sbench_b1.txt" 2> /dev/null
 python tools/sbench.py --batch 8 > "$O/sbench_b8.txt" 2> /dev/null
 python tools/rbench.py > "$O/rbench_b1.txt" 2> /dev/null
 python tools/rbench.py --batch 8 --iters 20 > "$O/rbench_b8.txt" 2> /dev/null
+python tools/sbench.py --batch 8 --size 368x1232 > "$O/sbench_b8_368x1232.txt" 2> /dev/null
+# lws_pool throughput matrix, the collective's cost under a world-of-one torchrun, and the two micro-benchmarks DESIGN.md cites
+GPU_MAX_HW_QUEUES=8 python tools/pool_bench.py --workers 2,3,4,6 > "$O/pool_bench_q8.txt" 2> /dev/null
+GPU_MAX_HW_QUEUES=4 python tools/pool_bench.py --workers 3,4 > "$O/pool_bench_q4.txt" 2> /dev/null
+python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 100 --warmup 10 --no-cpu-baseline > "$O/bench_torchrun_world1_b1.json" 2> /dev/null
+python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --batch 8 --steps 40 --warmup 5 --no-cpu-baseline > "$O/bench_torchrun_world1_b8.json" 2> /dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pipelined > "$O/bench_b1_steps20.json" 2> /dev/null
+python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-pipelined > "$O/bench_b1_steps200.json" 2> /dev/null
+(cd tools/micro && hipcc --offload-arch=gfx950 -O3 -o mfma4x4_bcast mfma4x4_bcast.hip && ./mfma4x4_bcast > "$O/micro_mfma4x4_bcast.txt" 2>&1; hipcc --offload-arch=gfx950 -O3 -o copybw copybw.hip && ./copybw 8 > "$O/micro_copybw_b8.txt" 2>&1; ./copybw 1 > "$O/micro_copybw_b1.txt" 2>&1)
+python tools/stamps.py mid8q3 8 > "$O/stamps_mid8q_stage3_b8.txt" 2> /dev/null
+python tools/stamps.py mid8q3 1 > "$O/stamps_mid8q_stage3_b1.txt" 2> /dev/null
+python tools/stamps.py mid8_3 8 > "$O/stamps_mid8_stage3_b8.txt" 2> /dev/null
+python -m lwsnet_amd.build --force > /dev/null 2>&1
