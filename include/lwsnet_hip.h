@@ -131,8 +131,8 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
 
 /* Launch-plan options of lws_forward / lws_disparity_stages.  They change which kernels / streams carry the work, never
  * the arithmetic: every setting returns the same bits (tests/test_gpu_parity.py::test_forward_schedule_options).
- *   "left_at"        -1 (default: by batch), 0 = refinement1_left starts with the forward, 2 = beside stages 2-3
- *   "split_heads"    -1 (default: batches >= 4), 0/1 = right-image feature head on its own stream
+ *   "left_at"        -1 (default: 2), 0 = refinement1_left starts with the forward, 2 = beside stages 2-3
+ *   "split_heads"    -1 (default: off), 0/1 = right-image feature head on its own stream
  *   "fuse_shift"     1 (default) = stage-1 volume built inside the first Conv3D launch
  *   "fuse_first"     1 (default) = refinement1_disp's 1 -> 32 convolution inside its first depthwise block
  *   "defer_upsample" 1 (default) = at batches <= 2 the consumers evaluate the stage-2/3 maps

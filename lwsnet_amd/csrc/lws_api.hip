@@ -420,8 +420,14 @@ static void bind_net2d(lws_ctx *h, const Net2dOffsets &o)
     n.r2_last = h->params + o.r2_last;
 }
 
-// right-image feature head on its own stream? (auto: batches >= 4)
-static bool split_heads(const lws_ctx *h, int B) { return h->opt.split_heads >= 0 ? h->opt.split_heads != 0 : B >= 4; }
+// right-image feature head on its own stream?  Auto = never: measured r03 (bench.py, left_at = 2): 2,793 vs 2,784 pairs/s at
+// batch 4, 2,896 vs 2,879 at batch 8, 799 vs 800 at 8 x 368x1232 without it (r01 had +4 % at batch 8 WITH it, while
+// refinement1_left still ran beside the feature head); -11 % at batch 1.  lws_set_option("split_heads", 1) forces it.
+static bool split_heads(const lws_ctx *h, int B)
+{
+    (void)B;
+    return h->opt.split_heads > 0;
+}
 
 // feature_extraction.forward (submodules.py:176-188) on N images; first layer may read two separate inputs
 static int feature_tail(lws_ctx *h, int N, int H, int W, const WsLayout &L, float *f8, float *f4, float *f2,
@@ -1224,12 +1230,13 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
         if (rc) return rc;
     }
     hipStream_t side = multi ? h->side : st;
-    // refinement1_left (5 kernels, 58 us of HBM-bound work at batch 1) depends on the left image only.  Small batches
-    // run it on the side stream beside stages 2 and 3, whose MFMA kernels keep their weights in registers and do not
-    // mind; beside the feature head it spilled into stage 1, where k_conv3d_mid16's weight stream from L2 does mind
-    // (measured r01: 1,953 vs 1,934 pairs/s at batch 1).  Large batches are throughput-bound and keep the early start
-    // (2,778 vs 2,760 pairs/s at batch 8).  lws_set_option("left_at", 0|2) forces either.
-    const int left_at = h->opt.left_at >= 0 ? h->opt.left_at : (B < 4 ? 2 : 0);
+    // refinement1_left (5 kernels, 58 us of HBM-bound work at batch 1) depends on the left image only.  It runs on the side
+    // stream beside stages 2 and 3, whose MFMA kernels keep their weights in registers and do not mind; beside the feature
+    // head it spilled into stage 1, where k_conv3d_mid16's weight stream from L2 does mind (measured r01: 1,953 vs 1,934
+    // pairs/s at batch 1; r03, with the refinement in cache-sized chunks: 2,784 vs 2,669 at batch 4, 2,879 vs 2,810 at
+    // batch 8, 800 vs 790 at 8 x 368x1232 -- k_conv3d_mid16 then runs at 0.79-0.80 of the fp32-MFMA peak in situ instead of
+    // 0.66).  lws_set_option("left_at", 0) starts it with the forward instead.
+    const int left_at = h->opt.left_at >= 0 ? h->opt.left_at : 2;
     // ev_fork orders both side streams behind everything already queued on st (the previous forward's readers of the
     // buffers they overwrite, the producers of left/right): recorded whenever either consumer of it runs -- the early
     // refinement1_left below or the right-image feature head on side2 (feature_extraction, batches >= 4)
