@@ -453,11 +453,15 @@ def main():
     h2, w2 = (H + 1) // 2, (W + 1) // 2
     warp_bytes = [(2 * 16 * (h2 // 2) * (w2 // 2) + 9 * (h2 // 2) * (w2 // 2) + (h2 // 2) * (w2 // 2)) * 4 * B,
                   (2 * 8 * h2 * w2 + 9 * h2 * w2 + h2 * w2) * 4 * B]
-    for name, nbytes in (("volume_l1_warp", sum(warp_bytes) / 2.0), ("ref_dws", 2.0 * B * H * W * 32 * 4),
-                         ("upsample_add", None), ("softargmin", (margs.maxdisplist[0] * (h2 // 4) * (w2 // 4) + H * W) * 4.0 * B)):
-        if name in kernels and nbytes:
+    # (per-step byte totals over the launches of a step: the refinement runs in chunks of pairs -- option ref_chunk_mb --, so a
+    # launch of k_ref_dws covers one chunk, not the batch)
+    for name, step_bytes in (("volume_l1_warp", float(sum(warp_bytes))), ("ref_dws", 12 * 2.0 * B * H * W * 32 * 4),
+                             ("softargmin", (margs.maxdisplist[0] * (h2 // 4) * (w2 // 4) + H * W) * 4.0 * B)):
+        if name in kernels:
+            nl = kernels[name]["launches_per_step"]
+            nbytes = step_bytes / nl
             gbs = nbytes / (kernels[name]["avg_us"] * 1e-6) / 1e9
-            hbm[name] = {"algorithmic_bytes_per_launch": int(nbytes), "avg_us": round(kernels[name]["avg_us"], 2),
+            hbm[name] = {"algorithmic_bytes_per_launch": int(nbytes), "launches_per_step": nl, "avg_us": round(kernels[name]["avg_us"], 2),
                          "achieved_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 4)}
 
     if rank != 0:
