@@ -114,25 +114,40 @@ def dry_run(args, rank, world):
     B = args.batch
     left_np, right_np = make_batch(B, 16, 32, first_index=rank * B)
     left, right = torch.from_numpy(left_np), torch.from_numpy(right_np)
-    gathered = None
     grouped = dist.is_initialized()
+    # the staged gather of the measured path (lwsnet_amd.dist.StagedGather), 2 steps per gather so that full buffers, the
+    # alternation of the two staging buffers and the tail flush all occur; step k "sees" pairs shifted by k so that a
+    # stale or misplaced slot cannot pass the check below
+    sg = ldist.StagedGather(B, 16, 32, 2, torch.device("cpu"))
+    nsteps = args.warmup + args.steps
     if grouped:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.warmup + args.steps):
-        pred = _dry_forward(left, right)
-        gathered = ldist.gather_pairs(pred[3], [B] * world, dst=0)
+    for k in range(nsteps):
+        pred = _dry_forward(left + k, right)
+        sg.slot().copy_(pred[3])
+        sg.commit()
+    sg.flush()
     if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ok = None
     if rank == 0:
-        # the gathered maps must be the unsharded result (pure partitioning)
+        # the last gather must hold, for every rank, exactly that rank's shard of the unsharded result of the last step(s)
         al, ar = make_batch(B * world, 16, 32, first_index=0)
-        ok = bool(torch.equal(gathered, _dry_forward(torch.from_numpy(al), torch.from_numpy(ar))[3]))
+        al, ar = torch.from_numpy(al), torch.from_numpy(ar)
+        ok = True
+        npairs = 0
+        for r in range(world):
+            got, nvalid = sg.gathered(r)
+            for j in range(nvalid):
+                k = nsteps - nvalid + j
+                want = _dry_forward(al + k, ar)[3][r * B:(r + 1) * B]
+                ok = ok and bool(torch.equal(got[j * B:(j + 1) * B], want))
+            npairs += B
         print(json.dumps({"metric": "stereo pairs/sec @256x512 maxdisp=192 (stage-4)", "value": None, "unit": "pairs/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
-                          "gather_equals_unsharded": ok, "pairs_gathered": int(gathered.shape[0]),
+                          "gather_equals_unsharded": ok, "pairs_gathered": npairs, "gathers": sg.count,
                           "wall_s": round(elapsed, 4),
                           "note": "CPU/gloo plumbing check with a stand-in forward; no GPU, nothing measured"}), flush=True)
     if grouped:
@@ -200,49 +215,29 @@ def main():
 
     grouped = dist.is_initialized()                      # torchrun launch (any world size, also 1): run the collective
     # The ONE collective of the path: stage-4 maps -> rank 0 (north_star: "a single RCCL gather for
-    # the output disparities" of a batch).  A gather carries at least 8 pairs per rank (the per-GPU batch of BASELINE
-    # config 4): with 1 pair per step the stage-4 maps of G = 8 consecutive steps are written straight into the slots of
-    # a staging buffer (lws_forward's output pointer) and gathered together -- measured r03 on one MI355X under torchrun,
-    # a gather per 0.5 ms step costs 9 % of the step (RCCL's send/recv kernel + two stream hand-offs per call), one per
-    # 8 steps 1 %.  Two staging buffers alternate, so the asynchronous gather of one overlaps the forwards that fill the
-    # other; every step's map is gathered inside the timed region (the tail is flushed before the clock stops).
-    G = max(1, -(-8 // B)) if grouped else 1
-    staging = [torch.empty((G * B, 1, H, W), device=dev) for _ in range(2)] if grouped else None
-    gathered = [[torch.empty((G * B, 1, H, W), device=dev) for _ in range(world)] for _ in range(2)] if (grouped and rank == 0) else [None, None]
-
+    # the output disparities" of a batch).  A gather carries at least 16 pairs per rank (8 MB at 256x512; BASELINE config 4
+    # gathers 8 per rank): with 1 pair per step the stage-4 maps of 16 consecutive steps are written straight into the slots
+    # of a staging buffer (lws_forward's output pointer) and gathered together (lwsnet_amd.dist.StagedGather) -- measured
+    # r03 on one MI355X under torchrun with 8 hardware queues: a gather per 0.5 ms step costs ~9 % of the step (RCCL's
+    # send/recv kernel + two stream hand-offs per call), one per 8 steps 2.3 %.  Two staging buffers alternate, so the
+    # asynchronous gather of one overlaps the forwards that fill the other; every step's map is gathered inside the timed
+    # region (the tail is flushed before the clock stops).
+    G = max(1, -(-16 // B)) if grouped else 1
+    sg = ldist.StagedGather(B, H, W, G, dev) if grouped else None
     counter = [0]
-    pending = [None, None]
-    gstate = {"slot": 0, "buf": 0, "count": 0}
-
-    def flush():
-        b = gstate["buf"]
-        pending[b] = ldist.gather_async(staging[b], gathered[b], dst=0)
-        gstate["count"] += 1
-        gstate["buf"], gstate["slot"] = 1 - b, 0
-        if pending[1 - b] is not None:                   # the buffer the next forwards write into: its gather must be done
-            pending[1 - b].wait()                        # (stream-side wait on the NCCL backend, not a host block)
-
-    def dest():
-        j = gstate["slot"]
-        return [None, None, None, staging[gstate["buf"]][j * B:(j + 1) * B]]
-
-    def gather_step():
-        gstate["slot"] += 1
-        if gstate["slot"] == G:
-            flush()
 
     def step():
         i = counter[0] % S
         counter[0] += 1
         if S == 1:
-            pred = models[0](left, right, out=dest() if grouped else None)
+            pred = models[0](left, right, out=[None, None, None, sg.slot()] if grouped else None)
             if grouped:
-                gather_step()
+                sg.commit()
             return pred
         with torch.cuda.stream(streams[i]):
-            pred = models[i](left, right, out=dest() if grouped else None)
+            pred = models[i](left, right, out=[None, None, None, sg.slot()] if grouped else None)
             if grouped:
-                gather_step()
+                sg.commit()
         return pred
 
     # spin-up (untimed, before the W warm-up steps): a short run started on an idle GPU measures the clock ramp, not the
@@ -270,29 +265,23 @@ def main():
     for m in models:
         _lib.check(lib.lws_profile_enable(m._h, 1 << KC_MID16), "lws_profile_enable")
         _lib.check(lib.lws_profile_sample(m._h, sample_every), "lws_profile_sample")
-    gstate["count"] = 0
     if grouped:
+        sg.count = 0
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pred = step()
-    last_buf, last_slot = gstate["buf"], gstate["slot"] - 1
     if grouped:
-        if gstate["slot"] > 0:                           # tail: the steps since the last full staging buffer
-            flush()
-        else:
-            last_buf, last_slot = 1 - gstate["buf"], G - 1
-        for w_ in pending:
-            if w_ is not None:
-                w_.wait()
+        sg.flush()                                       # tail gather + wait for everything in flight
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     gather_ok = None
-    if grouped and rank == 0:                            # rank 0's slot of the last gather holds this rank's last stage-4 map
-        gather_ok = bool(torch.equal(gathered[last_buf][0][last_slot * B:(last_slot + 1) * B], pred[3]))
+    if grouped and rank == 0:                            # rank 0's part of the last gather holds this rank's last stage-4 map
+        mine, nvalid = sg.gathered(0)
+        gather_ok = bool(torch.equal(mine[(nvalid - 1) * B:nvalid * B], pred[3]))
     tot = (ctypes.c_double * _lib.LWS_KC_COUNT)()
     cnt = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
     mid_ms, mid_n = 0.0, 0
@@ -538,7 +527,7 @@ def main():
     if grouped:
         out["collective"] = {"backend": dist.get_backend(),
                              "op": f"async gather of stage-4 maps to rank 0, one per {G} step(s) = {G * B} pairs per rank per gather",
-                             "gather_every_steps": G, "gathers_in_timed_region": gstate["count"],
+                             "gather_every_steps": G, "gathers_in_timed_region": sg.count,
                              "world": world, "rank0_slot_equals_local": gather_ok}
         if collective_overhead:
             base = collective_overhead["ms_per_step_without_gather"]

@@ -40,12 +40,24 @@ def main():
     work.wait()
     torch.cuda.synchronize()
     assert torch.equal(bufs[0], plain[3])
+    # the staged gather bench.py uses for 1 pair per step: 7 steps, 3 per gather -> two full buffers + a tail of one
+    sg = ldist.StagedGather(3, 64, 256, 3, dev)
+    maps = []
+    for k in range(7):
+        lk = left + 0.01 * k
+        maps.append(model(lk, right)[3].clone())
+        model(lk, right, out=[None, None, None, sg.slot()])
+        sg.commit()
+    sg.flush()
+    torch.cuda.synchronize()
+    got, nvalid = sg.gathered(0)
+    assert sg.count == 3 and nvalid == 1 and torch.equal(got[:3], maps[6]), "staged gather: tail slot differs"
     t = torch.tensor([1.5], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
     assert float(t.item()) == 1.5
     dist.destroy_process_group()
-    print("OK nccl world_size=1: sharded_forward and async gather bitwise equal to the plain forward")
+    print("OK nccl world_size=1: sharded_forward, async gather and staged gather bitwise equal to the plain forward")
 
 
 if __name__ == "__main__":
