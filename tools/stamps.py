@@ -30,6 +30,8 @@ m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
 lib = ctypes.CDLL(_lib.LIB_PATH)
 if kid == 18:
     m.set_option("mid8_form", 1)
+if kid == 2:
+    m.set_option("mid8_form", 0)
 if driver == "stack":
     shape = [(B, 24, 32, 64), (B, 9, 64, 128), (B, 9, 128, 256)][arg]
     c = torch.rand(shape, device=dev) * 12
