@@ -391,7 +391,11 @@ def main():
     # dominant kernel: stage-1 Conv3D c3 -> c3 (k_conv3d_mid16): 2*27*c3*c3 FLOP per voxel, voxels = B*D1*(H/8)*(W/8)
     c3 = margs.channels_3d * margs.growth_rate[0]
     h2_, w2_ = (H + 1) // 2, (W + 1) // 2                    # the stem gives ceil(H/2); the hourglass halves twice more
-    vox = B * margs.maxdisplist[0] * (h2_ // 4) * (w2_ // 4)
+    # pairs per launch: B, or B/2 when lws_forward splits a large batch over two streams (option split_batch: batches >= 8);
+    # read off the launch count of the breakdown pass rather than assumed
+    n_mid16 = kernels.get("conv3d_mid16", {}).get("launches_per_step", margs.layers_3d)
+    pairs_per_launch = B * margs.layers_3d / max(n_mid16, 1)
+    vox = pairs_per_launch * margs.maxdisplist[0] * (h2_ // 4) * (w2_ // 4)
     flop_per_launch = 2.0 * 27 * c3 * c3 * vox
     # algorithmic FLOPs of one forward: Conv3D stacks + 2D feature extractor (both images) + refinement
     L3 = margs.layers_3d
@@ -409,7 +413,7 @@ def main():
         roof = {"bound": "mfma", "kernel": "k_conv3d_mid16<32,3,4>", "achieved": round(achieved, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": None, "flop_per_launch": flop_per_launch, "avg_launch_us": round(mid["avg_us"], 2),
-                "timed_launches": int(mid_n), "timed_every_nth_step": sample_every}
+                "timed_launches": int(mid_n), "timed_every_nth_step": sample_every, "pairs_per_launch": pairs_per_launch}
     # the whole step against the same fp32-MFMA peak: algorithmic GF of a forward x pairs / step time.  This, not `frac`,
     # is how far the PATH is from the roofline (batch 1: 35 dependent launches, ~40 % of the step is fixed launch cost).
     step_tf = gf_pair * B / (1e3 * elapsed / args.steps) if elapsed > 0 else 0.0      # GF per ms = TF
@@ -420,11 +424,12 @@ def main():
     # second MFMA kernel of the path: the 8 -> 8 Conv3D layers of stages 2 and 3 (8 launches per step), from the untimed
     # breakdown pass (events around each launch, so each carries ~1-2 us of dispatch): USEFUL FLOPs / launch time
     secondary = None
-    if mid8_each and len(mid8_each) == 2 * L3 * nb and c3_s[1] == 8 and c3_s[2] == 8:
+    if mid8_each and len(mid8_each) % (2 * L3 * nb) == 0 and c3_s[1] == 8 and c3_s[2] == 8:
         per_stage = {}
+        ppl8 = B * (2 * L3 * nb) / len(mid8_each)              # pairs per launch (B, or B/2 under the batch split)
         for si, name in ((1, "stage2"), (2, "stage3")):
             us = [1e3 * mid8_each[k] for k in range(len(mid8_each)) if (k % (2 * L3)) // L3 == si - 1]
-            gf = 2.0 * 27 * 8 * 8 * vox_s[si] * B / 1e9
+            gf = 2.0 * 27 * 8 * 8 * vox_s[si] * ppl8 / 1e9
             avg = sum(us) / len(us)
             per_stage[name] = {"avg_launch_us": round(avg, 2), "useful_gflop_per_launch": round(gf, 4),
                                "achieved": round(gf / avg * 1e3, 2), "frac": round(gf / avg * 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
@@ -432,7 +437,7 @@ def main():
         tot_gf = sum(2.0 * 27 * 64 * vox_s[si] * B * L3 for si in (1, 2)) / 1e9
         secondary = {"kernel": "k_conv3d_mid8q<3,4>" if model.get_option("mid8_form") == 1 else "k_conv3d_mid8<3,4>",
                      "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS,
-                     "launches_per_step": 2 * L3, "us_per_step": round(tot_us, 2),
+                     "launches_per_step": len(mid8_each) // nb, "pairs_per_launch": ppl8, "us_per_step": round(tot_us, 2),
                      "achieved": round(tot_gf / tot_us * 1e3, 2), "frac": round(tot_gf / tot_us * 1e3 / PEAK_F32_MFMA_TFLOPS, 4), **per_stage,
                      "note": "useful FLOPs only; event pairs around each launch (untimed pass), not kernel timestamps"}
 
