@@ -367,6 +367,14 @@ def test_pool_returns_the_bits_of_forward(dev, model, side_streams):
         assert all(torch.equal(a, b) for a, b in zip(got3, model(l3, r3)))
         with pytest.raises(ValueError):
             pool.submit(np.zeros((1, 3, 375, 1242), np.float32), np.zeros((1, 3, 375, 1242), np.float32))
+    # destroying a pool with jobs still queued runs them first (lws_pool_destroy drains the queue, then joins the workers)
+    pool = model.pool(workers=2, side_streams=side_streams)
+    outs = [[torch.zeros((1, 1, 64, 256), device=dev) for _ in range(4)] for _ in range(6)]
+    for i in range(6):
+        pool.submit(lt[i:i + 1], rt[i:i + 1], out=outs[i])
+    pool.close()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for o, w in zip(outs, want) for a, b in zip(o, w))
     # LWSNet.map: the generator face of the same pool
     outs = list(model.map(((lt[i:i + 1], rt[i:i + 1]) for i in range(6)), workers=2))
     assert len(outs) == 6 and all(torch.equal(a, b) for o, w in zip(outs, want) for a, b in zip(o, w))
