@@ -147,8 +147,6 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "ref_chunk_mb"   72 (default): the refinement runs in chunks of pairs whose [b,H,W,32] maps are at most this many MB
  *                    each, so that a chunk's maps stay in the 256 MiB Infinity Cache between layers (batch 8 at 256x512:
  *                    two chunks of 4; 368x1232: one pair per chunk); 0 = one chunk
- *   "ref_order"      block -> tile order of the phase-grid refinement kernels: 0 (default) = dispatch order,
- *                    1 = XCD-contiguous, 2 = XCD-contiguous with the dilation phase slowest (measured r03: no gain)
  *   "device"         the HIP device the handle belongs to; settable only before lws_finalize / lws_reserve allocate
  * Unknown names and out-of-range values return LWS_ERR_INVALID. */
 int lws_set_option(lws_handle h, const char *name, int value);

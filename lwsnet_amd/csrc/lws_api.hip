@@ -818,11 +818,6 @@ static void apply_options(lws_ctx *h)
         h->stage[i].mid8_form = h->opt.mid8_form;
         h->stage[i].dfast = h->opt.conv3d_order;
     }
-    lws::Net2d &n = h->net2d;
-    for (int k = 0; k < 2; ++k)
-        for (int b = 0; b < 4; ++b) n.r1[k][b].order = h->opt.ref_order;
-    for (int b = 0; b < 4; ++b) n.r2[b].order = h->opt.ref_order;
-    n.r2_first.order = h->opt.ref_order;
 }
 
 static int *option_slot(lws_ctx *h, const char *name)
@@ -833,7 +828,6 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"fuse_first", &h->opt.fuse_first},
                                                      {"defer_upsample", &h->opt.defer_upsample},
                                                      {"side_streams", &h->opt.side_streams},
-                                                     {"ref_order", &h->opt.ref_order},
                                                      {"conv3d_order", &h->opt.conv3d_order},
                                                      {"ref_chunk_mb", &h->opt.ref_chunk_mb},
                                                      {"device", &h->device},
@@ -854,8 +848,6 @@ int lws_set_option(lws_handle h, const char *name, int value)
         LWS_CHECK_ARG(value >= -1 && value <= 1, "lws_set_option: split_heads must be -1 (auto), 0 or 1 (got %d)", value);
     else if (strcmp(name, "ref_chunk_mb") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 4096, "lws_set_option: ref_chunk_mb must be in 0..4096 (got %d)", value);
-    else if (strcmp(name, "ref_order") == 0)
-        LWS_CHECK_ARG(value >= 0 && value <= 2, "lws_set_option: ref_order must be 0, 1 or 2 (got %d)", value);
     else if (strcmp(name, "device") == 0) {
         LWS_CHECK_ARG(value >= 0, "lws_set_option: device must be >= 0 (got %d)", value);
         LWS_CHECK_ARG(h->params == nullptr && h->ws == nullptr && h->side == nullptr,

@@ -127,14 +127,12 @@ struct Conv2dLayer {
 // Refinement: BatchNorm(32) -> ReLU -> depthwise 3x3 (dil) -> pointwise 32->32
 struct RefDws {
     int dil = 1;
-    int order = 0;         // block -> tile order (option "ref_order", ref_tile in lws_conv2d.hip)
     float *bn_s = nullptr, *bn_t = nullptr;
     float *dw = nullptr;   // [tap][32]
     float *pw = nullptr;   // MFMA A fragments [q][mt][lane][4]
 };
 
 struct RefConv64 {
-    int order = 0;
     float *bn_s = nullptr, *bn_t = nullptr;   // [64]
     float *w = nullptr;                       // MFMA A fragments [tap][qq][mt][lane][4]
 };
@@ -168,7 +166,6 @@ struct lws_ctx {
         int side_streams = 1;      // 0: no handle-owned side streams, the whole forward on the caller's stream (lws_pool workers)
         int conv3d_order = 1;      // tile order of the Conv3D stacks: 0 = x fastest, 1 = d fastest (halo planes shared inside an XCD's L2)
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
-        int ref_order = 0;         // block -> tile order of the phase-grid refinement kernels (0 = dispatch order, 1/2 = XCD-contiguous)
     } opt;
     unsigned prof_mask = 0;                  // kernel classes being timed in the current call
     unsigned prof_mask_cfg = 0;              // ... as configured by lws_profile_enable

@@ -613,35 +613,21 @@ struct RefTile {
     int b, Y0, X0;
 };
 
-// order (launch-plan option "ref_order", speed only -- the tiles partition the image under every order):
-//   0  dispatch order: block id -> (phase fastest, bx, by, image).  Consecutive blocks, i.e. DIFFERENT XCDs, own the
-//      phases of one image block; a tile's halo neighbours (same phase, adjacent image block) sit d*d or nbx*d*d blocks
-//      away, in another XCD's L2 whenever d*d is not a multiple of 8.
-//   1  XCD-contiguous: each XCD walks one contiguous run of that same list (xcd_tile), so all phases of an image block
-//      and its neighbours stream through ONE L2.
-//   2  XCD-contiguous with the phase slowest inside an image: consecutive tiles of an XCD are halo neighbours.
-__device__ __forceinline__ RefTile ref_tile(int dil, int nbx, int nby, int tile_rows = RT_Y, int order = 0)
+// Block -> tile: dispatch order, the dilation phase fastest (consecutive blocks own the phases of one image block).  Measured
+// r03 and removed: XCD-contiguous runs of that list, and the phase slowest inside an XCD's run -- 66.0 vs 69.3 / 67.2 us per
+// k_ref_dws launch at 8 x 256x512 (profiles/r03/experiments/rbench_b8_ref_order.txt): the halo re-reads already hit L2 / the
+// Infinity Cache (tools/micro/copybw.hip: a phase-grid copy costs the same with and without the halo).
+__device__ __forceinline__ RefTile ref_tile(int dil, int nbx, int nby, int tile_rows = RT_Y)
 {
-    int bid = order == 0 ? (int)blockIdx.x : xcd_tile(blockIdx.x, gridDim.x);
+    int bid = blockIdx.x;
     const int d2 = dil * dil;
-    int phase, bx, by;
-    if (order == 2) {
-        bx = bid % nbx;
-        bid /= nbx;
-        by = bid % nby;
-        bid /= nby;
-        phase = bid % d2;
-        bid /= d2;
-    } else {
-        phase = bid % d2;
-        bid /= d2;
-        bx = bid % nbx;
-        bid /= nbx;
-        by = bid % nby;
-        bid /= nby;
-    }
+    const int phase = bid % d2;
+    bid /= d2;
+    const int bx = bid % nbx;
+    bid /= nbx;
+    const int by = bid % nby;
     RefTile t;
-    t.b = bid;
+    t.b = bid / nby;
     t.Y0 = by * tile_rows * dil + phase / dil;
     t.X0 = bx * RT_X * dil + phase % dil;
     return t;
@@ -674,8 +660,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
                                                  const float *__restrict__ bn_t, const float *__restrict__ dw,   // [tap][32]
                                                  const float4 *__restrict__ pwpk,                              // [q][mt][lane]
                                                  float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt,
-                                                 const float *__restrict__ plow, int ph, int pw, float *__restrict__ pmat,
-                                                 int order)
+                                                 const float *__restrict__ plow, int ph, int pw, float *__restrict__ pmat)
 {
     // (FIRST only) plow != nullptr: the disparity map has not been materialised -- it is evaluated on demand as
     // upsample(plow [ph,pw]) + in (DeferredMap) and this workgroup writes its own tile pixels of it to pmat (the
@@ -683,7 +668,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
     __shared__ float4 sA[8 * DWS_SA];
     __shared__ float4 sB[8 * DWS_SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const RefTile t = ref_tile(dil, nbx, nby, RT_Y, order);
+    const RefTile t = ref_tile(dil, nbx, nby);
     LWS_STAMPK(5, 0);
 
     const int c4 = tid & 7;
@@ -853,14 +838,13 @@ template <int TY, int NW>   // tile rows, waves per workgroup (TY/NW rows each)
 __global__ __launch_bounds__(64 * NW) void k_ref_conv64(const float *__restrict__ inL, const float *__restrict__ inD,
                                                     const float *__restrict__ bn_s, const float *__restrict__ bn_t,   // [64]
                                                     const float4 *__restrict__ wpk,   // [tap][qq][mt][lane]
-                                                    float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt,
-                                                    int order)
+                                                    float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt)
 {
     constexpr int HY = TY + 2, NPX = HY * RH_X, RW = TY / NW, NT = 64 * NW;
     static_assert(TY % NW == 0 && RW >= 1 && RW <= 4, "rows must split evenly over the waves");
     __shared__ __attribute__((aligned(16))) float sA[2 * NPX * RVS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const RefTile t = ref_tile(dil, nbx, nby, TY, order);
+    const RefTile t = ref_tile(dil, nbx, nby, TY);
     const int n = lane & 15, g = lane >> 4;
     LWS_STAMPK(6, 0);
 
@@ -1055,7 +1039,7 @@ int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, i
     dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
     hipLaunchKernelGGL(k_ref_dws<false>, grid, block, 0, st, in, (const float *)nullptr, l.bn_s, l.bn_t, l.dw,
                        reinterpret_cast<const float4 *>(l.pw), out, H, W, l.dil, nbx, nby,
-                       use_wt_stores((size_t)B * H * W * 128), (const float *)nullptr, 0, 0, (float *)nullptr, l.order);
+                       use_wt_stores((size_t)B * H * W * 128), (const float *)nullptr, 0, 0, (float *)nullptr);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -1074,7 +1058,7 @@ int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst,
     dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
     hipLaunchKernelGGL(k_ref_dws<true>, grid, block, 0, st, img, wfirst, l.bn_s, l.bn_t, l.dw,
                        reinterpret_cast<const float4 *>(l.pw), out, H, W, l.dil, nbx, nby,
-                       use_wt_stores((size_t)B * H * W * 128), plow, ph, pw, pmat, l.order);
+                       use_wt_stores((size_t)B * H * W * 128), plow, ph, pw, pmat);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -1089,7 +1073,7 @@ int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, fl
         dim3 grid(nbx * nby * dil * dil * B), block(64 * NWv);                                                      \
         hipLaunchKernelGGL((k_ref_conv64<TYv, NWv>), grid, block, 0, st, inL, inD, l.bn_s, l.bn_t,                   \
                            reinterpret_cast<const float4 *>(l.w), out, H, W, dil, nbx, nby,                         \
-                           use_wt_stores((size_t)B * H * W * 128), l.order);                                        \
+                           use_wt_stores((size_t)B * H * W * 128));                                                 \
     }
     // 8-row tiles, 4 waves x 2 rows (46 KB LDS: 3 workgroups per CU): 50.5 / 349 us at B = 1 / 8 (r01, 256x512; the floor
     // is 31 / 246 us of fp32 MFMA issue).  Measured and dropped: 4-row tiles x 4 waves 54.3 / 390 us, 4-row x 2 waves

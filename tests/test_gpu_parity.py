@@ -190,20 +190,19 @@ def test_feature_extraction_golden(dev, model):
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 64, 256), (2, 40, 72), (1, 136, 152), (1, 63, 255)])
-@pytest.mark.parametrize("ref_order", [0, 1, 2])
-def test_refine_bitexact(dev, model, B, H, W, ref_order):
-    """ref_order: block -> tile order of the phase-grid kernels (dispatch order / XCD-contiguous / phase slowest): the
-    tiles partition the image under every order, so the bits cannot change."""
+@pytest.mark.parametrize("chunk_mb", [72, 1])
+def test_refine_bitexact(dev, model, B, H, W, chunk_mb):
+    """chunk_mb = 1: the refinement runs one pair per chunk (option ref_chunk_mb; pairs are independent, so the same bits)."""
     from lwsnet_amd import ops
     from oracle import c_oracle as C
     rng = np.random.default_rng(9)
     left = rng.standard_normal((B, 3, H, W)).astype(np.float32)
     pred3 = (rng.random((B, 1, H, W)) * 150.0).astype(np.float32)
-    model.set_option("ref_order", ref_order)
+    model.set_option("ref_chunk_mb", chunk_mb)
     try:
         got = ops.refine(model._h, cu(left, dev), cu(pred3, dev))
     finally:
-        model.set_option("ref_order", 0)
+        model.set_option("ref_chunk_mb", 72)
     assert_bits(got, C.refine(left, pred3, model.state_dict()), "refine")
 
 
@@ -274,7 +273,7 @@ def test_forward_repeatable_batch8(dev, model):
 
 
 OPTION_PLANS = [{"left_at": 0}, {"left_at": 2}, {"split_heads": 1}, {"split_heads": 0}, {"fuse_shift": 0},
-                {"fuse_first": 0}, {"defer_upsample": 0}, {"mid8_form": 1}, {"mid8_form": 0}, {"ref_order": 1}, {"ref_order": 2},
+                {"fuse_first": 0}, {"defer_upsample": 0}, {"mid8_form": 1}, {"mid8_form": 0},
                 {"conv3d_order": 1}, {"conv3d_order": 0}, {"ref_chunk_mb": 0}, {"ref_chunk_mb": 1},
                 {"side_streams": 0}, {"side_streams": 0, "left_at": 0}, {"left_at": 2, "split_heads": 1},
                 {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0, "mid8_form": 1}]
