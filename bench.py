@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--size", default="256x512", help="HxW of the synthetic pairs (default: BASELINE config 2)")
     ap.add_argument("--feature-fp16", action="store_true", help="BASELINE config 5: fp16-rounded feature maps")
     ap.add_argument("--maxdisp0", type=int, default=24, help="stage-1 hypotheses (24 = maxdisp 192, 32 = maxdisp 256)")
+    ap.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed forwards before the warm-up steps (clock ramp of an idle GPU)")
+    ap.add_argument("--gather-pairs", type=int, default=8, help="minimum pairs per rank carried by one RCCL gather (staged gather)")
     ap.add_argument("--opt", action="append", default=[], help="name=value launch-plan option (lws_set_option); experiments only")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check without a GPU: gloo, per-pair stand-in forward, value = null (tests only)")
@@ -215,14 +217,16 @@ def main():
 
     grouped = dist.is_initialized()                      # torchrun launch (any world size, also 1): run the collective
     # The ONE collective of the path: stage-4 maps -> rank 0 (north_star: "a single RCCL gather for
-    # the output disparities" of a batch).  A gather carries at least 16 pairs per rank (8 MB at 256x512; BASELINE config 4
-    # gathers 8 per rank): with 1 pair per step the stage-4 maps of 16 consecutive steps are written straight into the slots
-    # of a staging buffer (lws_forward's output pointer) and gathered together (lwsnet_amd.dist.StagedGather) -- measured
-    # r03 on one MI355X under torchrun with 8 hardware queues: a gather per 0.5 ms step costs ~9 % of the step (RCCL's
-    # send/recv kernel + two stream hand-offs per call), one per 8 steps 2.3 %.  Two staging buffers alternate, so the
-    # asynchronous gather of one overlaps the forwards that fill the other; every step's map is gathered inside the timed
-    # region (the tail is flushed before the clock stops).
-    G = max(1, -(-16 // B)) if grouped else 1
+    # the output disparities" of a batch).  A gather carries at least 8 pairs per rank (4 MB at 256x512: what BASELINE config 4
+    # gathers per rank): with 1 pair per step the stage-4 maps of 8 consecutive steps are written straight into the slots of a
+    # staging buffer (lws_forward's output pointer) and gathered together (lwsnet_amd.dist.StagedGather).  Measured r03 on
+    # one MI355X under torchrun with 8 hardware queues (tools/gather_probe.py, profiles/r03/experiments/gather_overhead.txt):
+    # an isolated gather completes in ~46 us whatever its size (host call 25-30 us), but beside a running forward it delays
+    # the step by ~30 / 80 / 140 / 1,000 us at 0.5 / 2 / 4 / 8 MB (RCCL's send/recv kernel shares the CUs and takes more
+    # channels for larger messages): 5.9-7.8 % of a 0.5 ms step with a gather per step, 3.6-4.1 % with 4 or 8 pairs per gather,
+    # 14-18 % with 16.  Two staging buffers alternate, so the asynchronous gather of one overlaps the forwards that fill the
+    # other; every step's map is gathered inside the timed region (the tail is flushed before the clock stops).
+    G = max(1, -(-args.gather_pairs // B)) if grouped else 1
     sg = ldist.StagedGather(B, H, W, G, dev) if grouped else None
     counter = [0]
 
@@ -243,14 +247,20 @@ def main():
     # spin-up (untimed, before the W warm-up steps): a short run started on an idle GPU measures the clock ramp, not the
     # path -- the driver's --steps 20 --warmup 5 is 13 ms of GPU work and read 3.5 % below --steps 200 (r03).  Forwards for
     # SPINUP_S seconds first; then W warm-up steps; then exactly K timed steps.
-    SPINUP_S = 0.3
+    SPINUP_S = max(0.0, args.spinup)
     t_spin = time.perf_counter()
-    n_spin = 0
-    while time.perf_counter() - t_spin < SPINUP_S:
-        for _ in range(10):
+    n_spin, prev, settled = 0, None, False
+    # at least SPINUP_S seconds, then until two consecutive blocks of 25 forwards take the same time within 1 % (<= 2 s in all)
+    while SPINUP_S > 0 and (time.perf_counter() - t_spin < SPINUP_S or (not settled and time.perf_counter() - t_spin < 2.0)):
+        t1 = time.perf_counter()
+        for _ in range(25):
             models[n_spin % S](left, right)
             n_spin += 1
         torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        settled = prev is not None and abs(dt - prev) <= 0.01 * prev
+        prev = dt
+    spun_s = time.perf_counter() - t_spin
     for _ in range(args.warmup):
         step()
     # inside the timed region only the dominant kernel class is bracketed by hipEvents (8 events per step);
@@ -518,7 +528,7 @@ def main():
     out = {
         "metric": "stereo pairs/sec @256x512 maxdisp=192 (stage-4)",
         "value": round(pairs / elapsed, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "spinup_s": SPINUP_S, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+        "warmup": args.warmup, "spinup_s": round(spun_s, 3), "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp16-rounded features)" if args.feature_fp16 else "f32", "data": "synthetic",
         "config": {"workload": (f"BASELINE config 2: batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[24,5,5], all 4 stages"
                                 if (H, W, args.maxdisp0) == (256, 512, 24) else
