@@ -201,6 +201,7 @@ def main():
 
     margs = default_args(maxdisplist=(args.maxdisp0, 5, 5), feature_fp16=args.feature_fp16)
     sd = make_state_dict(7, margs)
+    c3_first = margs.channels_3d * margs.growth_rate[0]
     S = max(1, args.streams)
     models = [LWSNet(margs, device=dev).set_state_dict(sd).eval() for _ in range(S)]
     for o in args.opt:
@@ -385,6 +386,38 @@ def main():
                      "what": f"lws_pool (C ABI): {P} C++ worker threads, each with a clone of the model and ONE HIP stream, keep "
                              f"{2 * P} batch-{B} forwards in flight so that their launch-bound chains overlap on the device; median of "
                              "3 timed repetitions; not the headline: `value` is the single-stream number"}
+    # untimed extra (single GPU, default single-stream run only): the same steps with option mid16_form = 1 -- the stage-1
+    # 32 -> 32 Conv3D layers on split-bf16 MFMA (k_conv3d_mid16x: three bf16 values per float32 operand, six exact cross
+    # products accumulated in float32).  An opt-in numerics mode: float32-level accuracy (tests/test_gpu_parity.py::
+    # test_split_bf16_*), NOT bit-exact against the oracle chain, therefore never `value` and reported with its own dtype.
+    split_bf16 = None
+    if not grouped and S == 1 and not args.no_pipelined and model.get_option("mid16_form") == 0 and c3_first == 32:
+        model.set_option("mid16_form", 1)
+        try:
+            for _ in range(10):
+                px = model(left, right)
+            _lib.check(lib.lws_profile_enable(model._h, 1 << KC_MID16), "lws_profile_enable")
+            _lib.check(lib.lws_profile_sample(model._h, 8), "lws_profile_sample")
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nx = max(args.steps, 100)
+            for _ in range(nx):
+                px = model(left, right)
+            torch.cuda.synchronize()
+            dtx = time.perf_counter() - t1
+            totx = (ctypes.c_double * _lib.LWS_KC_COUNT)()
+            cntx = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
+            _lib.check(lib.lws_profile_read(model._h, totx, cntx), "lws_profile_read")
+            _lib.check(lib.lws_profile_enable(model._h, 0), "lws_profile_enable")
+            x_us = 1e3 * totx[KC_MID16] / max(cntx[KC_MID16], 1)
+            diff = [round(float((px[s_] - pred[s_]).abs().max()), 6) for s_ in range(4)]
+            split_bf16 = {"value": round(B * nx / dtx, 2), "unit": "pairs/s", "steps": nx, "ms_per_step": round(1e3 * dtx / nx, 4),
+                          "dtype": "f32 activations / weights split into 3 x bf16 for the stage-1 32->32 Conv3D MFMAs, f32 accumulate",
+                          "k_conv3d_mid16x_avg_launch_us": round(x_us, 2), "max_abs_vs_exact_per_stage": diff,
+                          "what": "option mid16_form = 1: not bit-exact against the oracle chain (float32-level accuracy, gated by "
+                                  "the float64 noise-floor tests); an opt-in numerics mode, never the headline"}
+        finally:
+            model.set_option("mid16_form", 0)
     if grouped:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -536,6 +569,7 @@ def main():
                    "pairs_per_gpu": B, "streams": S, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4 per {G * B} pairs per rank" if grouped else "single GPU",
                    "weights": "seeded synthetic (seed 7, calibrated BN)", "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), **({"options": args.opt} if args.opt else {})},
         "roofline": _with_traffic(roof, B), "secondary": secondary, "cpu_baseline": cpu, "latency_ms": latency, "pipelined": pipelined,
+        "split_bf16": split_bf16,
         "hbm_kernels": hbm,
         "hot_path_kernel_ms_per_step": round(hot_ms, 4), "all_kernel_ms_per_step": round(all_ms, 4), "kernels": {k: {a: round(b, 2) for a, b in v.items()} for k, v in kernels.items()},
     }

@@ -130,7 +130,8 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
                 void *stream);
 
 /* Launch-plan options of lws_forward / lws_disparity_stages.  They change which kernels / streams carry the work, never
- * the arithmetic: every setting returns the same bits (tests/test_gpu_parity.py::test_forward_schedule_options).
+ * the arithmetic: every setting returns the same bits (tests/test_gpu_parity.py::test_forward_schedule_options) -- with ONE
+ * exception, "mid16_form" = 1, an opt-in numerics mode (see below).
  *   "left_at"        -1 (default: 2), 0 = refinement1_left starts with the forward, 2 = beside stages 2-3
  *   "split_heads"    -1 (default: off), 0/1 = right-image feature head on its own stream
  *   "fuse_shift"     1 (default) = stage-1 volume built inside the first Conv3D launch
@@ -140,6 +141,10 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *                    broadcast (k_conv3d_mid8q: 4 couts x 64 voxels per instruction, no padding), 0 = v_mfma_f32_16x16x4_f32
  *                    with rows = (x parity, cout) (k_conv3d_mid8: 25 % of every instruction is structural zero padding;
  *                    measured r03 8-17 % slower)
+ *   "mid16_form"     0 (default) = the 32 -> 32 Conv3D layers on the f32-input MFMA, the oracle's fma chain bit for bit;
+ *                    1 = k_conv3d_mid16x: split-bf16 MFMA (each float32 operand as three bf16 values, six exact cross
+ *                    products accumulated in float32): ~2.5x the MFMA issue rate at float32-level accuracy, but NOT
+ *                    bit-exact -- an opt-in numerics mode, never what bench.py's headline measures
  *   "conv3d_order"   tile order of the Conv3D kernels inside an XCD's run: 1 (default) = d fastest (the tiles that share
  *                    halo planes are co-resident: re-reads hit that XCD's L2), 0 = x fastest
  *   "side_streams"   1 (default) = refinement1_left and the feature-extractor tail run on handle-owned side streams;

@@ -817,6 +817,7 @@ static void apply_options(lws_ctx *h)
     for (int i = 0; i < 3; ++i) {
         h->stage[i].mid8_form = h->opt.mid8_form;
         h->stage[i].dfast = h->opt.conv3d_order;
+        h->stage[i].mid16_form = h->opt.mid16_form;
     }
 }
 
@@ -829,6 +830,7 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"defer_upsample", &h->opt.defer_upsample},
                                                      {"side_streams", &h->opt.side_streams},
                                                      {"conv3d_order", &h->opt.conv3d_order},
+                                                     {"mid16_form", &h->opt.mid16_form},
                                                      {"ref_chunk_mb", &h->opt.ref_chunk_mb},
                                                      {"device", &h->device},
                                                      {"mid8_form", &h->opt.mid8_form}};

@@ -109,6 +109,7 @@ struct Conv3dLayer {
 struct Stage3d {
     int c3 = 0;
     int mid8_form = 1;                 // 8 -> 8 layers: 0 = k_conv3d_mid8 (16x16x4, parity rows), 1 = k_conv3d_mid8q (4x4x1_16B)
+    int mid16_form = 0;                // 32 -> 32 layers: 0 = k_conv3d_mid16 (f32 MFMA, the oracle's chain), 1 = k_conv3d_mid16x (split-bf16, not bit-exact)
     int dfast = 1;                     // tile order of the stack's kernels: 0 = x, y, d; 1 = d fastest (tile_coords, lws_conv3d.hip)
     std::vector<Conv3dLayer> layers;   // layers_3d + 2
 };
@@ -164,6 +165,7 @@ struct lws_ctx {
         int defer_upsample = 1;    // batches <= 2: consumers evaluate the stage-2/3 maps (no k_upsample_add launches)
         int mid8_form = 1;         // 8 -> 8 Conv3D layers: 0 = k_conv3d_mid8 (16x16x4), 1 = k_conv3d_mid8q (4x4x1_16B, no zero padding)
         int side_streams = 1;      // 0: no handle-owned side streams, the whole forward on the caller's stream (lws_pool workers)
+        int mid16_form = 0;        // 1: stage-1 middle Conv3D layers on split-bf16 MFMA (k_conv3d_mid16x): float32-level accuracy, NOT bit-exact
         int conv3d_order = 1;      // tile order of the Conv3D stacks: 0 = x fastest, 1 = d fastest (halo planes shared inside an XCD's L2)
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
     } opt;

@@ -307,6 +307,264 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
 }
 
 // =============================================================================================
+// Middle layers, C3 == 32, split-bf16 form (k_conv3d_mid16x; option "mid16_form" = 1, NOT the default and never what
+// bench.py's headline measures: it is not bit-exact against the oracle chain).
+//
+// The f32-input MFMA runs at the float32 vector rate (157 TF); the bf16 MFMA at 16x that.  Every float32 operand is split
+// into three bf16 values x = hi + mid + lo (8 + 8 + 8 mantissa bits) and a product a*b is replaced by the six cross terms of
+// total order <= 2 -- lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi, each exact in float32 -- accumulated in float32 by
+// v_mfma_f32_16x16x32_bf16 (K = the 32 input channels of one tap per instruction).  Six 16-cycle instructions replace eight
+// 32-cycle ones: 2.5-2.6x the issue rate (tools/micro/split_bf16.hip: 107-114 against 277-285 cycles per (tap, accumulator)),
+// at float32-level accuracy: on a K = 864 contraction of ReLU'd activations with Kaiming weights the result sits 3.2e-6 (max) /
+// 5.3e-7 (mean) from float64, the float32 fma chain 2.7e-6 / 4.9e-7 (same file).  What it cannot be is bit-identical to that
+// chain, so it is gated by the float64 noise-floor tests (tests/test_gpu_parity.py::test_split_bf16_*) instead of the oracle.
+//
+// Same tile, same interface and same epilogue as k_conv3d_mid16 (float32 channels-last in and out): the split happens
+// while the halo tile is staged into LDS ([voxel][variant hi/mid/lo][32 channels] bf16, 208-byte voxel stride), the
+// weights are pre-split on the host into A fragments [tap][mt][variant][lane][8] and streamed one tap ahead.
+// =============================================================================================
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// float32 -> bf16 bits, round to nearest even (finite values; the activations are BN + ReLU outputs)
+__host__ __device__ __forceinline__ uint32_t f2bf_bits(float x)
+{
+    union { float f; uint32_t u; } v;
+    v.f = x;
+    return (v.u + 0x7FFFu + ((v.u >> 16) & 1u)) >> 16;
+}
+__host__ __device__ __forceinline__ float bf_bits2f(uint32_t h)
+{
+    union { float f; uint32_t u; } v;
+    v.u = h << 16;
+    return v.f;
+}
+// x -> (hi, mid, lo) bf16 bit patterns; every subtraction is exact in float32
+__host__ __device__ __forceinline__ void split_bf16x3(float x, uint32_t &hi, uint32_t &mid, uint32_t &lo)
+{
+    hi = f2bf_bits(x);
+    const float r1 = x - bf_bits2f(hi);
+    mid = f2bf_bits(r1);
+    const float r2 = r1 - bf_bits2f(mid);
+    lo = f2bf_bits(r2);
+}
+
+// device form for two values at once: v_cvt_pk_bf16_f32 (round to nearest even, the same rounding as f2bf_bits) -- 11
+// instructions per pair instead of ~40 for the bit arithmetic; result dwords hold (x0's, x1's) bf16 in (low, high) halves
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b)
+{
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2_ __attribute__((ext_vector_type(2)));
+    const f2_ v = {a, b};
+    const b2_ r = __builtin_convertvector(v, b2_);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ void split_bf16x3_pair(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l)
+{
+    h = pack_bf16x2(x0, x1);
+    float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = pack_bf16x2(r0, r1);
+    r0 = r0 - __uint_as_float(m << 16);
+    r1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = pack_bf16x2(r0, r1);
+}
+
+template <int TD, int TY>
+struct Mid16xCfg {
+    static constexpr int C3 = 32, MT = 2, NW = 4, NT = 256;
+    static constexpr int ROWS = TD * TY, RW = ROWS / NW;
+    static constexpr int HD = TD + 2, HY = TY + 2, HX = 18;
+    static constexpr int VSB = 208;                  // LDS voxel stride in bytes: 3 variants x 64 B + 16 B (ds_read_b128 of 16 neighbouring voxels spreads over the banks)
+    static constexpr int NVOX = HD * HY * HX;
+    static constexpr int ITEMS = NVOX * 2;           // (voxel, 16-channel group)
+    static constexpr int SITER = (ITEMS + NT - 1) / NT;
+    static constexpr int LDS_BYTES = NVOX * VSB;
+    static constexpr int TAP_U4 = MT * 3 * 64;       // uint4 (8 bf16) per tap in the packed weights
+    static_assert(ROWS % NW == 0, "rows must split evenly over the waves");
+};
+
+template <int TD, int TY>
+__global__ __launch_bounds__(256) void k_conv3d_mid16x(const float *__restrict__ in,      // [B,D,h,w,32]
+                                                       const uint4 *__restrict__ wpk,     // [29][2][3][64] x 8 bf16
+                                                       const float *__restrict__ bn_s,    // next layer BN [32]
+                                                       const float *__restrict__ bn_t,
+                                                       float *__restrict__ out, int D, int h, int w,
+                                                       int tiles_x, int tiles_y, int tord)
+{
+    using Cfg = Mid16xCfg<TD, TY>;
+    constexpr int C3 = 32, MT = 2, RW = Cfg::RW, HY = Cfg::HY, HX = Cfg::HX, VSB = Cfg::VSB, NT = Cfg::NT, SITER = Cfg::SITER;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned char *ldsb = reinterpret_cast<unsigned char *>(lds);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    int tx, ty, td;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
+    const int b = blockIdx.y;
+    const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
+    const float *inb = in + (int64_t)b * D * h * w * C3;
+
+    // ---- stage: item = (voxel, 16-channel group) = 64 B of float32 -> 3 x 32 B of bf16 (hi / mid / lo)
+    float4 c[SITER][4];
+    bool okv[SITER];
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int it = tid + i * NT;
+        const int q = it & 1, v = it >> 1;
+        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        okv[i] = it < Cfg::ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        const float4 *src = reinterpret_cast<const float4 *>(inb + (okv[i] ? (((int64_t)gd * h + gy) * w + gx) * C3 + q * 16 : 0));
+        c[i][0] = src[0];
+        c[i][1] = src[1];
+        c[i][2] = src[2];
+        c[i][3] = src[3];
+    }
+    // next layer's BatchNorm of this lane's output channels, and the first tap's weights, behind the halo loads
+    float4 es[MT], et[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        es[mt] = *reinterpret_cast<const float4 *>(bn_s + mt * 16 + 4 * g);
+        et[mt] = *reinterpret_cast<const float4 *>(bn_t + mt * 16 + 4 * g);
+    }
+    const uint4 *wp = wpk + lane;
+    uint4 wa[3][MT][3];                             // ring over kw: tap (kd,kh,kw) lives in slot kw; the stream runs TWO taps ahead
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            wa[0][mt][t] = wp[(mt * 3 + t) * 64];
+            wa[1][mt][t] = wp[Cfg::TAP_U4 + (mt * 3 + t) * 64];
+        }
+    // two phases as in k_conv3d_mid16: the kd = 0 taps only read halo planes [0, TD), i.e. the items of iterations i < P1
+    constexpr int P1 = (TD * HY * HX * 2 + NT - 1) / NT < SITER ? (TD * HY * HX * 2 + NT - 1) / NT : SITER;
+    auto stage_write = [&](int i) {
+        const int it = tid + i * NT;
+        if (it < Cfg::ITEMS) {
+            const int q = it & 1, v = it >> 1;
+            uint32_t pk[3][8];                      // per variant: 16 bf16 = 8 dwords
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xs[4] = {c[i][k].x, c[i][k].y, c[i][k].z, c[i][k].w};
+#pragma unroll
+                for (int e = 0; e < 4; e += 2)
+                    split_bf16x3_pair(okv[i] ? xs[e] : 0.f, okv[i] ? xs[e + 1] : 0.f, pk[0][2 * k + e / 2], pk[1][2 * k + e / 2],
+                                      pk[2][2 * k + e / 2]);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                uint4 *dst = reinterpret_cast<uint4 *>(ldsb + v * VSB + t * 64 + q * 32);
+                dst[0] = make_uint4(pk[t][0], pk[t][1], pk[t][2], pk[t][3]);
+                dst[1] = make_uint4(pk[t][4], pk[t][5], pk[t][6], pk[t][7]);
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < P1; ++i) stage_write(i);
+    __syncthreads();
+
+    floatx4 acc[RW][MT];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    // per-row LDS base of this lane: voxel (rd, ry, n) of the halo tile, channels 8 g .. 8 g + 7 of each variant
+    const unsigned char *rptr[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = wave * RW + r;
+        rptr[r] = ldsb + ((row / TY * HY + row % TY) * HX + n) * VSB + g * 16;
+    }
+    auto as_frag = [](const uint4 &u) {
+        union { uint4 u4; bf16x8 v; } cv;
+        cv.u4 = u;
+        return cv.v;
+    };
+    // activation fragments of one tap: RW rows x (hi, mid, lo); double-buffered by tap parity inside a (kd,kh) iteration --
+    // 3 taps per iteration, so the buffers of consecutive iterations are reconciled with one copy per iteration
+    uint4 bb[2][RW][3];
+    auto load_b = [&](uint4 (&dst)[RW][3], int off) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) dst[r][t] = *reinterpret_cast<const uint4 *>(rptr[r] + off + t * 64);
+    };
+    load_b(bb[0], 0);
+
+#pragma unroll 1
+    for (int kdh = 0; kdh < 9; ++kdh) {
+        const int kd = kdh / 3, kh = kdh - kd * 3;
+        const int base = (kd * HY + kh) * HX * VSB;
+        const int kn = kdh < 8 ? kdh + 1 : 8;                          // (clamped: the prefetch of the last iteration is unused)
+        const int base_n = ((kn / 3) * HY + (kn % 3)) * HX * VSB;
+        const uint4 *wtap = wp + (size_t)(kdh * 3) * Cfg::TAP_U4;
+        if (P1 < SITER && kdh == 3) {
+            // phase 2 of the staging (halo planes TD, TD + 1, first read by kd = 1); the fragments prefetched at the end of
+            // iteration 2 may predate these writes: read again
+#pragma unroll
+            for (int i = P1; i < SITER; ++i) stage_write(i);
+            __syncthreads();
+            load_b(bb[0], base);
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int cb = kw & 1, nb = cb ^ 1;                         // compile-time buffers: kw = 0, 1, 2 -> 0, 1, 0
+            // prefetch: the next tap's activation fragments, and the weights of tap + 2 into the slot of tap - 1
+            load_b(bb[nb], kw < 2 ? base + (kw + 1) * VSB : base_n);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) wa[(kw + 2) % 3][mt][t] = wtap[(size_t)(kw + 2) * Cfg::TAP_U4 + (mt * 3 + t) * 64];
+            // (fence: left to itself hipcc sinks every prefetch to its first use and waits on it there)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const bf16x8 bh = as_frag(bb[cb][r][0]), bm = as_frag(bb[cb][r][1]), bl = as_frag(bb[cb][r][2]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8 ah = as_frag(wa[kw][mt][0]), am = as_frag(wa[kw][mt][1]), al = as_frag(wa[kw][mt][2]);
+                    floatx4 a = acc[r][mt];                 // smallest terms first
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, a, 0, 0, 0);
+                    acc[r][mt] = a;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // kw = 2 prefetched the next iteration's first tap into buffer 1; iterations start from buffer 0
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bb[0][r][t] = bb[1][r][t];
+    }
+
+    // ---- epilogue (as k_conv3d_mid16): row i = 4 (lane >> 4) + reg = output channel in the tile, col = lane & 15 = voxel
+    float *outb = out + (int64_t)b * D * h * w * C3;
+    const int gx = x0 + n;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = wave * RW + r;
+        const int gd = d0 + row / TY, gy = y0 + row % TY;
+        if (gd < D && gy < h && gx < w) {
+            float *o = outb + (((int64_t)gd * h + gy) * w + gx) * C3;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float4 s = es[mt], t = et[mt];
+                float4 v;
+                v.x = bn_relu(acc[r][mt][0], s.x, t.x);
+                v.y = bn_relu(acc[r][mt][1], s.y, t.y);
+                v.z = bn_relu(acc[r][mt][2], s.z, t.z);
+                v.w = bn_relu(acc[r][mt][3], s.w, t.w);
+                store_act4(o + mt * 16 + 4 * g, v, 0);
+            }
+        }
+    }
+}
+
+// =============================================================================================
 // Middle layers, C3 == 8 (stages 2 and 3).
 //
 // With only 8 output channels a 16-row MFMA tile would be half empty.  Instead the 16 rows are
@@ -959,7 +1217,9 @@ constexpr size_t MID8_PACK = 72 * 64;      // k_conv3d_mid8's fragments; k_conv3
 size_t packed_mid_weight_floats(int c3)
 {
     if (c3 == 8) return MID8_PACK + 28 * 64;
-    return (size_t)29 * c3 * c3;   // 27 taps + two all-zero taps (branch-free two-taps-ahead prefetch in k_conv3d_mid16)
+    // 27 taps + two all-zero taps (branch-free two-taps-ahead prefetch in k_conv3d_mid16); C3 == 32: + the split-bf16
+    // fragments of k_conv3d_mid16x, 29 taps (two all-zero) x 2 cout tiles x 3 variants x 64 lanes x 8 bf16 = 16 B each
+    return (size_t)29 * c3 * c3 + (c3 == 32 ? (size_t)29 * 2 * 3 * 64 * 4 : 0);
 }
 
 // w: [cout][cin][27] (Conv3D weight [Cout,Cin,3,3,3] flattened)
@@ -991,6 +1251,19 @@ void pack_mid_weights(const float *w, int c3, float *out)
         return;
     }
     const int Q = c3 / 16, MT = c3 / 16;
+    if (c3 == 32) {
+        // k_conv3d_mid16x: lane l of (tap, mt, variant) holds W[16 mt + (l & 15)][cin = 8 (l >> 4) + j][tap], j = 0..7, as bf16
+        uint16_t *ox = reinterpret_cast<uint16_t *>(out + (size_t)29 * c3 * c3);
+        for (int tap = 0; tap < 29; ++tap)
+            for (int mt = 0; mt < 2; ++mt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int cout = 16 * mt + (lane & 15), cin = 8 * (lane >> 4) + j;
+                        uint32_t v[3] = {0, 0, 0};
+                        if (tap < 27) split_bf16x3(w[((size_t)cout * c3 + cin) * 27 + tap], v[0], v[1], v[2]);
+                        for (int t = 0; t < 3; ++t) ox[((((size_t)tap * 2 + mt) * 3 + t) * 64 + lane) * 8 + j] = (uint16_t)v[t];
+                    }
+    }
     for (int tap = 0; tap < 27; ++tap)
         for (int q = 0; q < Q; ++q)
             for (int mt = 0; mt < MT; ++mt)
@@ -1099,6 +1372,29 @@ static int mid16_launch(const Stage3d &s, int layer, const float *in, float *out
 }
 
 template <int TD, int TY>
+static int mid16x_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w, hipStream_t st,
+                         hipEvent_t e0, hipEvent_t e1)
+{
+    using Cfg = Mid16xCfg<TD, TY>;
+    static std::atomic<uint64_t> attr_done{0};
+    {
+        const int rc_ = ensure_dyn_lds(attr_done, reinterpret_cast<const void *>(&k_conv3d_mid16x<TD, TY>), Cfg::LDS_BYTES);
+        if (rc_) return rc_;
+    }
+    const int tiles_x = cdiv(w, 16), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
+    dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
+    const uint4 *wx = reinterpret_cast<const uint4 *>(s.layers[layer].w + (size_t)29 * 32 * 32);
+    if (e0 != nullptr)
+        hipExtLaunchKernelGGL((k_conv3d_mid16x<TD, TY>), grid, block, Cfg::LDS_BYTES, st, e0, e1, 0, in, wx, s.layers[layer + 1].bn_s,
+                              s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
+    else
+        hipLaunchKernelGGL((k_conv3d_mid16x<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in, wx, s.layers[layer + 1].bn_s,
+                           s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
+template <int TD, int TY>
 static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w,
                        hipStream_t st)
 {
@@ -1152,6 +1448,7 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
         }
         case 16: return mid16_launch<16, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
         case 32: {
+            if (s.mid16_form == 1) return mid16x_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
             // (8-wave workgroups <32,3,4,4,2> and half-height tiles <32,3,2,2,2> measured within 1 % of this, r01)
             return mid16_launch<32, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
         }

@@ -461,6 +461,66 @@ def test_forward_within_reference_source_noise_floor(dev, hip_lib, name, factor)
     print(name, "(|HIP - fp64|, |reference fp32 - fp64|) per stage:", report)
 
 
+def test_split_bf16_forward_on_the_float32_noise_floor(dev, hip_lib):
+    """Option mid16_form = 1 (k_conv3d_mid16x): the stage-1 32 -> 32 Conv3D layers on split-bf16 MFMA (three bf16 values per
+    float32 operand, six exact cross products accumulated in float32).  It is NOT bit-exact against the oracle chain and is
+    never the default or the benchmark headline.  VERDICT r2 item 8's condition -- no further from float64 than the float32
+    chain is -- cannot be a single-sample comparison (two float32 builds of this chaotic pipeline differ from each other by as
+    much as either differs from float64), so it is asserted on aggregates over six pairs (five seeded smooth pairs and the
+    white-noise pair) against the float64 literal oracle: per stage, mean |split - fp64| <= 1.15 x mean |exact - fp64| and
+    max <= 1.5 x max (+1e-4 px).  Measured r03 (tools/split_bf16_numerics.py, 8 pairs): means 3.16e-5 / 8.64e-5 / 2.82e-4 /
+    3.46e-4 px against the exact build's 3.14e-5 / 8.84e-5 / 2.97e-4 / 3.63e-4."""
+    from lwsnet_amd.models import LWSNet
+    from lwsnet_amd.synth import make_noise_pair, make_pair
+    from oracle import lws_oracle
+    sd = make_state_dict(7)
+    m = LWSNet(default_args(), device=dev).set_state_dict(sd).eval()
+    H, W, npairs = 64, 256, 6
+    agg = {k: {"max": np.zeros(4), "mean": np.zeros(4)} for k in ("exact", "split")}
+    differs = False
+    for i in range(npairs):
+        l, r = make_noise_pair(H, W, 0) if i == npairs - 1 else make_pair(H, W, 40 + i)[:2]
+        l, r = l[None], r[None]
+        ref64 = lws_oracle.forward(l, r, sd, (24, 5, 5), dtype=torch.float64)
+        m.set_option("mid16_form", 0)
+        exact = [p.clone() for p in m(l, r)]
+        m.set_option("mid16_form", 1)
+        split = m(l, r)
+        differs = differs or any(not torch.equal(a, b) for a, b in zip(exact, split))
+        for name, res in (("exact", exact), ("split", split)):
+            for s in range(4):
+                e = (res[s].cpu().double() - ref64[s]).abs()
+                agg[name]["max"][s] = max(agg[name]["max"][s], float(e.max()))
+                agg[name]["mean"][s] += float(e.mean()) / npairs
+    print("mean |. - fp64| per stage: exact", agg["exact"]["mean"], "split-bf16", agg["split"]["mean"])
+    print("max  |. - fp64| per stage: exact", agg["exact"]["max"], "split-bf16", agg["split"]["max"])
+    assert differs                                                        # the option really selects the other kernel
+    for s in range(4):
+        assert agg["split"]["mean"][s] <= 1.15 * agg["exact"]["mean"][s] + 1e-6, (s, agg)
+        assert agg["split"]["max"][s] <= 1.5 * agg["exact"]["max"][s] + 1e-4, (s, agg)
+
+
+def test_split_bf16_stack_close_to_the_exact_chain(dev, model):
+    """lws_conv3d_stack, stage 1 (C3 = 32) with mid16_form = 1 against the C oracle's exact chain: float32-level agreement
+    (six layers deep; tools/micro/split_bf16.hip measures 3.2e-6 vs 2.7e-6 from float64 for one layer at output scale 4.7),
+    on a ragged shape too (tile edges, D not a multiple of 3)."""
+    from lwsnet_amd import ops
+    from oracle import c_oracle as C
+    for shape in [(1, 24, 32, 64), (2, 23, 10, 40)]:
+        c = (np.random.default_rng(5).random(shape) * 12.0).astype(np.float32)
+        want = C.conv3d_stack(c, model.state_dict(), 0)
+        model.set_option("mid16_form", 1)
+        try:
+            got = ops.conv3d_stack(model._h, 0, cu(c, dev)).cpu().numpy()
+        finally:
+            model.set_option("mid16_form", 0)
+        scale = float(np.abs(want).max())
+        err = float(np.abs(got - want).max())
+        print(f"split-bf16 stack {shape}: max |diff| {err:.3e} at output scale {scale:.3f}")
+        assert err <= 2e-5 * scale and err > 0.0
+        assert_bits(ops.conv3d_stack(model._h, 0, cu(c, dev)), want, "exact form restored")
+
+
 def test_forward_odd_size_vs_reference_source(dev, model):
     """63x255 against the stage maps the reference's own source produced (tests/golden/ref_source_e2e_odd_63x255.npz):
     no further from its float64 run than 1.5x its float32 run is."""
