@@ -6,12 +6,12 @@ src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03"
 os.makedirs(dst, exist_ok=True)
 for f in os.listdir(dst):
-    if f != "README.md":
+    if f != "README.md" and os.path.isfile(os.path.join(dst, f)):      # (experiments/ holds outputs of other runs: kept)
         os.remove(os.path.join(dst, f))
 shutil.copy(f"{src}/kt/run_kernel_stats.csv", f"{dst}/kernel_stats_b1_256x512.csv")
 shutil.copy(f"{src}/kt_bench.json", f"{dst}/bench_under_rocprof.json")
 for n in os.listdir(src):
-    if (n.startswith("bench_") and n.endswith(".json")) or n.startswith(("sbench_", "rbench_", "pool_bench_", "micro_", "stamps_")):
+    if (n.startswith("bench_") and n.endswith(".json")) or n.startswith(("sbench_", "rbench_", "pool_bench_", "micro_", "stamps_", "split_bf16_", "gather_probe")):
         shutil.copy(f"{src}/{n}", f"{dst}/{n}")
 for d, name in (("kt8", "kernel_stats_b8_256x512.csv"), ("ktc3", "kernel_stats_b8_368x1232.csv")):
     if os.path.isfile(f"{src}/{d}/run_kernel_stats.csv"):

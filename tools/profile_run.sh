@@ -44,3 +44,6 @@ python tools/stamps.py mid8q3 8 > "$O/stamps_mid8q_stage3_b8.txt" 2> /dev/null
 python tools/stamps.py mid8q3 1 > "$O/stamps_mid8q_stage3_b1.txt" 2> /dev/null
 python tools/stamps.py mid8_3 8 > "$O/stamps_mid8_stage3_b8.txt" 2> /dev/null
 python -m lwsnet_amd.build --force > /dev/null 2>&1
+python tools/split_bf16_numerics.py --pairs 8 > "$O/split_bf16_numerics_64x256.txt" 2> /dev/null
+(cd tools/micro && hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o split_bf16 split_bf16.hip && ./split_bf16 > "$O/micro_split_bf16.txt" 2>&1)
+python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29535 tools/gather_probe.py 2> /dev/null | grep pairs > "$O/gather_probe.txt"
