@@ -46,6 +46,7 @@ def main():
         tot = (ctypes.c_double * _lib.LWS_KC_COUNT)()
         cnt = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
         _lib.check(lib.lws_profile_read(m._h, tot, cnt))
+        per_launch = None
         each = (ctypes.c_float * 8192)()
         n_each = ctypes.c_int(0)
         _lib.check(lib.lws_profile_read_class(m._h, 10, each, 8192, ctypes.byref(n_each)))      # LWS_KC_REF_DWS
@@ -55,12 +56,14 @@ def main():
             nch = max(1, per // 12)          # chunks: refinement1_left of every chunk first, then the rest of every chunk
             dil = [2, 4, 8, 16] * nch + [2, 4, 8, 16, 8, 4, 2, 1] * nch
             avg = [sum(each[k * per + j] for k in range(a.iters)) / a.iters * 1e3 for j in range(per)]
-            print("   ref_dws per launch (dilation: us): " + "  ".join(f"d{d}:{u:.1f}" for d, u in zip(dil, avg)))
+            per_launch = "   ref_dws per launch (dilation: us): " + "  ".join(f"d{d}:{u:.1f}" for d, u in zip(dil, avg))
         _lib.check(lib.lws_profile_enable(m._h, 0))
         print(f"ref_chunk_mb={fuse} B={a.batch} {H}x{W}: wall {wall * 1e6:.1f} us per lws_refine; kernels (with event overhead):")
         for kc in range(_lib.LWS_KC_COUNT):
             if cnt[kc]:
                 print(f"   {lib.lws_kernel_class_name(kc).decode():12s} x{cnt[kc] // a.iters:2d} avg {tot[kc] / cnt[kc] * 1e3:7.2f} us")
+        if per_launch:
+            print(per_launch)
     print("bitwise equal:", bool(torch.equal(outs[72], outs[0])))
 
 
