@@ -478,7 +478,7 @@ def main():
                                "achieved": round(gf / avg * 1e3, 2), "frac": round(gf / avg * 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
         tot_us = sum(1e3 * v for v in mid8_each) / nb
         tot_gf = sum(2.0 * 27 * 64 * vox_s[si] * B * L3 for si in (1, 2)) / 1e9
-        secondary = {"kernel": "k_conv3d_mid8q<3,4>" if model.get_option("mid8_form") == 1 else "k_conv3d_mid8<3,4>",
+        secondary = {"kernel": "k_conv3d_mid8q (3x4x32 / 3x8x32 tiles by grid size)" if model.get_option("mid8_form") == 1 else "k_conv3d_mid8<3,4>",
                      "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS,
                      "launches_per_step": len(mid8_each) // nb, "pairs_per_launch": ppl8, "us_per_step": round(tot_us, 2),
                      "achieved": round(tot_gf / tot_us * 1e3, 2), "frac": round(tot_gf / tot_us * 1e3 / PEAK_F32_MFMA_TFLOPS, 4), **per_stage,

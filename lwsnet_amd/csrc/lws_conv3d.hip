@@ -1443,7 +1443,18 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
             // 8.7 vs 7.8 at B = 1, 13.4 vs 12.2 at B = 2, 32.5 vs 29.0 at B = 8; stage 3 (9 x 128 x 256) 17.6 vs 15.9, 30.0 vs 28.8,
             // 105.0 vs 94.8; 8 x 368x1232: 102 vs 85 and 369 vs 328.  (Without the two-phase staging the 4x4x1 form lost at
             // 8 x 9x64x128 and 2 x 9x128x256: 34.5 and 33.3 us.)
-            if (s.mid8_form == 1) return mid8q_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+            if (s.mid8_form == 1) {
+                // Tile: 3 x 8 x 32 voxels (12 waves, 54 KB of LDS, halo 2.21x) once there are enough of them to fill the chip,
+                // else 3 x 4 x 32 (6 waves, 32.6 KB, halo 2.66x).  The staging is what bounds this kernel (the CU's fetch path),
+                // so 17 % fewer halo bytes per output are worth more than the smaller tile's occupancy -- measured r03
+                // (tools/sbench.py, one run, us per launch, small -> large tile): 8 x 9x128x256 95.3 -> 81.2 (100 TF useful =
+                // 0.64 of the peak), 8 x 9x64x128 30.4 -> 24.1, 2 x 9x128x256 29.3 -> 23.2, 2 x 9x64x128 12.4 -> 10.7,
+                // 8 x 9x184x616 332 -> 303, 8 x 9x92x308 85.9 -> 78.1; 1 x 9x128x256 (384 large tiles) 16.3 -> 16.3;
+                // 1 x 9x64x128 (96 large tiles) 7.8 -> 9.4: hence the threshold.
+                const long big_tiles = (long)cdiv(w, 32) * cdiv(h, 8) * cdiv(D, 3) * B;
+                if (big_tiles >= 192) return mid8q_launch<3, 8>(s, layer, act_in, act_out, B, D, h, w, st);
+                return mid8q_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+            }
             return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
         }
         case 16: return mid16_launch<16, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);

@@ -29,10 +29,10 @@ __global__ __launch_bounds__(256) void k_copy(const float4 *in, float4 *out, siz
     if (i < n4) out[i] = in[i];
 }
 
-// phase-grid tile copy: workgroup = 8 x 16 pixels of one phase (y mod d, x mod d); thread = (pixel, 4-channel group);
+// phase-grid tile copy: workgroup = TYv x TXv pixels of one phase (y mod d, x mod d); thread = (pixel, 4-channel group);
 // HALO: also read (and discard) the 1-pixel halo ring of the phase grid, as a 3x3 dilated stencil does
-template <bool HALO>
-__global__ __launch_bounds__(256) void k_phase(const float4 *in, float4 *out, float *sink, int d, int nbx, int nby)
+template <bool HALO, int TYv, int TXv, int NTv>
+__global__ __launch_bounds__(NTv) void k_phase(const float4 *in, float4 *out, float *sink, int d, int nbx, int nby)
 {
     int bid = blockIdx.x;
     const int d2 = d * d, phase = bid % d2;
@@ -40,23 +40,24 @@ __global__ __launch_bounds__(256) void k_phase(const float4 *in, float4 *out, fl
     const int bx = bid % nbx;
     bid /= nbx;
     const int by = bid % nby, b = bid / nby;
-    const int Y0 = by * 8 * d + phase / d, X0 = bx * 16 * d + phase % d;
+    const int Y0 = by * TYv * d + phase / d, X0 = bx * TXv * d + phase % d;
     const int c4 = threadIdx.x & 7;
     const float4 *inb = in + (size_t)b * H * W * 8;
     float4 acc = make_float4(0, 0, 0, 0);
-    constexpr int NP = HALO ? 180 : 128, IT = (NP * 8 + 255) / 256;
+    constexpr int HXv = TXv + 2, NP = HALO ? (TYv + 2) * HXv : TYv * TXv, PPI = NTv / 8, IT = (NP + PPI - 1) / PPI;
+    constexpr int OT = TYv * TXv / PPI;
     float4 v[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int hp = (threadIdx.x >> 3) + 32 * i;
+        const int hp = (threadIdx.x >> 3) + PPI * i;
         int gy, gx;
         if (HALO) {
-            const int hy = hp / 18, hx = hp - hy * 18;
+            const int hy = hp / HXv, hx = hp - hy * HXv;
             gy = Y0 + (hy - 1) * d;
             gx = X0 + (hx - 1) * d;
         } else {
-            gy = Y0 + (hp >> 4) * d;
-            gx = X0 + (hp & 15) * d;
+            gy = Y0 + (hp / TXv) * d;
+            gx = X0 + (hp % TXv) * d;
         }
         const bool ok = hp < NP && gy >= 0 && gy < H && gx >= 0 && gx < W;
         v[i] = inb[ok ? ((size_t)gy * W + gx) * 8 + c4 : 0];
@@ -70,9 +71,9 @@ __global__ __launch_bounds__(256) void k_phase(const float4 *in, float4 *out, fl
     }
     float4 *outb = out + (size_t)b * H * W * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = (threadIdx.x >> 3) + 32 * i;
-        const int gy = Y0 + (p >> 4) * d, gx = X0 + (p & 15) * d;
+    for (int i = 0; i < OT; ++i) {
+        const int p = (threadIdx.x >> 3) + PPI * i;
+        const int gy = Y0 + (p / TXv) * d, gx = X0 + (p % TXv) * d;
         if (gy < H && gx < W) outb[((size_t)gy * W + gx) * 8 + c4] = HALO ? acc : v[i];
     }
     if (acc.x == 12345.678f) sink[0] = 1.f;
@@ -119,10 +120,29 @@ int main(int argc, char **argv)
     for (int d : {1, 2, 4, 8, 16}) {
         const int nbx = (W + 16 * d - 1) / (16 * d), nby = (H + 8 * d - 1) / (8 * d);
         const unsigned g = (unsigned)(nbx * nby * d * d * B);
-        us = timeit([&](int i) { k_phase<false><<<g, 256>>>(buf[i % 3], buf[(i + 1) % 3], sink, d, nbx, nby); }, 30);
+        us = timeit([&](int i) { k_phase<false, 8, 16, 256><<<g, 256>>>(buf[i % 3], buf[(i + 1) % 3], sink, d, nbx, nby); }, 30);
         printf("phase-grid copy d=%-2d : %7.1f us  %5.2f TB/s (algorithmic read + write)\n", d, us, 2 * MB / us);
-        us = timeit([&](int i) { k_phase<true><<<g, 256>>>(buf[i % 3], buf[(i + 1) % 3], sink, d, nbx, nby); }, 30);
+        us = timeit([&](int i) { k_phase<true, 8, 16, 256><<<g, 256>>>(buf[i % 3], buf[(i + 1) % 3], sink, d, nbx, nby); }, 30);
         printf("  ... with halo  d=%-2d : %7.1f us  %5.2f TB/s (algorithmic; the halo re-reads 1.41x)\n", d, us, 2 * MB / us);
+    }
+    // larger phase-grid tiles with the halo: 8 x 32 (halo 1.33x) and 16 x 16 (1.27x), 256 and 512 threads
+    for (int d : {1, 2, 8, 16}) {
+        {
+            const int nbx = (W + 32 * d - 1) / (32 * d), nby = (H + 8 * d - 1) / (8 * d);
+            const unsigned g = (unsigned)(nbx * nby * d * d * B);
+            us = timeit([&](int i) { k_phase<true, 8, 32, 256><<<g, 256>>>(buf[i % 3], buf[(i + 1) % 3], sink, d, nbx, nby); }, 30);
+            printf("tile  8x32 halo d=%-2d 256 thr: %7.1f us  %5.2f TB/s\n", d, us, 2 * MB / us);
+            us = timeit([&](int i) { k_phase<true, 8, 32, 512><<<g, 512>>>(buf[i % 3], buf[(i + 1) % 3], sink, d, nbx, nby); }, 30);
+            printf("tile  8x32 halo d=%-2d 512 thr: %7.1f us  %5.2f TB/s\n", d, us, 2 * MB / us);
+        }
+        {
+            const int nbx = (W + 16 * d - 1) / (16 * d), nby = (H + 16 * d - 1) / (16 * d);
+            const unsigned g = (unsigned)(nbx * nby * d * d * B);
+            us = timeit([&](int i) { k_phase<true, 16, 16, 256><<<g, 256>>>(buf[i % 3], buf[(i + 1) % 3], sink, d, nbx, nby); }, 30);
+            printf("tile 16x16 halo d=%-2d 256 thr: %7.1f us  %5.2f TB/s\n", d, us, 2 * MB / us);
+            us = timeit([&](int i) { k_phase<true, 16, 16, 512><<<g, 512>>>(buf[i % 3], buf[(i + 1) % 3], sink, d, nbx, nby); }, 30);
+            printf("tile 16x16 halo d=%-2d 512 thr: %7.1f us  %5.2f TB/s\n", d, us, 2 * MB / us);
+        }
     }
     return 0;
 }
