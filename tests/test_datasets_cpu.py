@@ -8,7 +8,6 @@ import pytest
 from PIL import Image
 
 from lwsnet_amd import datasets as D
-from lwsnet_amd.logger import AverageMeter, log_file_name, setup_logger
 from lwsnet_amd.synth import IMAGENET_MEAN, IMAGENET_STD
 
 
@@ -115,20 +114,3 @@ def test_stereo_pairs_sceneflow_eval_pads_four_rows(tmp_path):
         l[:, 4:, :], ((left.astype(np.float32) / 255 - IMAGENET_MEAN) / IMAGENET_STD).transpose(2, 0, 1), atol=1e-6)
     from lwsnet_amd.synth import check_size
     check_size(544, 960, 32)                                     # BASELINE config 5's geometry is legal
-
-
-def test_logger_and_average_meter(tmp_path):
-    assert log_file_name("train.py", now=0).startswith("train_py-19") and log_file_name("a/b.py", now=0).startswith("a-")
-    log = setup_logger("unit_test.py", str(tmp_path / "log"))
-    log.info("hello %d", 7)
-    assert setup_logger("unit_test.py", str(tmp_path / "log")) is log
-    files = os.listdir(tmp_path / "log")
-    assert len(files) == 1 and files[0].startswith("unit_test_py-") and files[0].endswith(".log")
-    for h in log.handlers:
-        h.flush()
-    text = (tmp_path / "log" / files[0]).read_text()
-    assert "INFO: hello 7" in text and "test_datasets_cpu.py:" in text
-    m = AverageMeter()
-    m.update(2.0)
-    m.update(4.0, n=3)
-    assert m.val == 4.0 and m.count == 4 and m.avg == pytest.approx(3.5)
