@@ -140,7 +140,7 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "mid8_form"      the 8 -> 8 Conv3D layers (stages 2, 3): 1 (default) = v_mfma_f32_4x4x1_16B_f32 with the A block
  *                    broadcast (k_conv3d_mid8q: 4 couts x 64 voxels per instruction, no padding), 0 = v_mfma_f32_16x16x4_f32
  *                    with rows = (x parity, cout) (k_conv3d_mid8: 25 % of every instruction is structural zero padding;
- *                    measured r03 8-17 % slower)
+ *                    measured r03 10-25 % slower); k_conv3d_mid8q picks 3 x 8 x 32 or 3 x 4 x 32 voxel tiles by grid size
  *   "mid16_form"     0 (default) = the 32 -> 32 Conv3D layers on the f32-input MFMA, the oracle's fma chain bit for bit;
  *                    1 = k_conv3d_mid16x: split-bf16 MFMA (each float32 operand as three bf16 values, six exact cross
  *                    products accumulated in float32): ~2.5x the MFMA issue rate at float32-level accuracy, but NOT
@@ -163,8 +163,8 @@ typedef enum {
     LWS_KC_VOLUME_SHIFT = 0,   /* k_volume_l1_shift                      */
     LWS_KC_VOLUME_WARP = 1,    /* k_volume_l1_warp                       */
     LWS_KC_CONV3D_FIRST = 2,   /* k_conv3d_first  (1 -> C3)              */
-    LWS_KC_CONV3D_MID16 = 3,   /* k_conv3d_mid16  (C3 -> C3, C3 % 16 == 0, fp32 MFMA) */
-    LWS_KC_CONV3D_MID8 = 4,    /* k_conv3d_mid8   (8 -> 8, fp32 MFMA)    */
+    LWS_KC_CONV3D_MID16 = 3,   /* k_conv3d_mid16 / k_conv3d_mid16x (C3 -> C3, C3 % 16 == 0, MFMA) */
+    LWS_KC_CONV3D_MID8 = 4,    /* k_conv3d_mid8q / k_conv3d_mid8 (8 -> 8, fp32 MFMA) */
     LWS_KC_CONV3D_LAST = 5,    /* k_conv3d_last   (C3 -> 1, + skip)      */
     LWS_KC_SOFTARGMIN = 6,     /* k_softargmin                           */
     LWS_KC_UPSAMPLE = 7,       /* k_upsample_add                         */
