@@ -40,6 +40,7 @@ import torch         # noqa: E402
 
 H, W = 256, 512
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+PEAK_BF16_MFMA_TFLOPS = 2516.6        # same table: 16 x the f32-input rate ("~2.5 PF dense")
 
 
 def _sha256(path):
@@ -268,7 +269,7 @@ def main():
     # the per-class breakdown comes from a separate, untimed pass below
     # and only on every n-th step (its begin/end events keep the next kernel from being queued behind it: ~3 us
     # of extra gap per timed launch at batch 1) -- at least ~48 timed launches with the default 50 steps.
-    KC_MID16 = 3
+    KC_MID16, KC_CONV64 = 3, 11          # LWS_KC_CONV3D_MID16, LWS_KC_REF_CONV64 (include/lwsnet_hip.h)
     # every 4th step at least: a kernel bracketed by its own events keeps its successor from being queued behind it
     # (~3 us each at batch 1), so timing EVERY step of a short run (the driver's --steps 20) taxed the headline by 3-4 %
     # (VERDICT r2).  20 steps -> 5 sampled steps -> 20 timed launches.
@@ -386,17 +387,19 @@ def main():
                      "what": f"lws_pool (C ABI): {P} C++ worker threads, each with a clone of the model and ONE HIP stream, keep "
                              f"{2 * P} batch-{B} forwards in flight so that their launch-bound chains overlap on the device; median of "
                              "3 timed repetitions; not the headline: `value` is the single-stream number"}
-    # untimed extra (single GPU, default single-stream run only): the same steps with option mid16_form = 1 -- the stage-1
-    # 32 -> 32 Conv3D layers on split-bf16 MFMA (k_conv3d_mid16x: three bf16 values per float32 operand, six exact cross
-    # products accumulated in float32).  An opt-in numerics mode: float32-level accuracy (tests/test_gpu_parity.py::
+    # untimed extra (single GPU, default single-stream run only): the same steps with options mid16_form = conv64_form = 1 --
+    # the stage-1 32 -> 32 Conv3D layers and refinement2[0] on split-bf16 MFMA (k_conv3d_mid16x, k_ref_conv64x: three bf16
+    # values per float32 operand, six exact cross products accumulated in float32).  An opt-in numerics mode: float32-level accuracy (tests/test_gpu_parity.py::
     # test_split_bf16_*), NOT bit-exact against the oracle chain, therefore never `value` and reported with its own dtype.
     split_bf16 = None
-    if not grouped and S == 1 and not args.no_pipelined and model.get_option("mid16_form") == 0 and c3_first == 32:
+    if (not grouped and S == 1 and not args.no_pipelined and model.get_option("mid16_form") == 0
+            and model.get_option("conv64_form") == 0 and c3_first == 32):
         model.set_option("mid16_form", 1)
+        model.set_option("conv64_form", 1)
         try:
             for _ in range(10):
                 px = model(left, right)
-            _lib.check(lib.lws_profile_enable(model._h, 1 << KC_MID16), "lws_profile_enable")
+            _lib.check(lib.lws_profile_enable(model._h, (1 << KC_MID16) | (1 << KC_CONV64)), "lws_profile_enable")
             _lib.check(lib.lws_profile_sample(model._h, 8), "lws_profile_sample")
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -410,14 +413,18 @@ def main():
             _lib.check(lib.lws_profile_read(model._h, totx, cntx), "lws_profile_read")
             _lib.check(lib.lws_profile_enable(model._h, 0), "lws_profile_enable")
             x_us = 1e3 * totx[KC_MID16] / max(cntx[KC_MID16], 1)
+            x64_us = 1e3 * totx[KC_CONV64] / max(cntx[KC_CONV64], 1)
             diff = [round(float((px[s_] - pred[s_]).abs().max()), 6) for s_ in range(4)]
             split_bf16 = {"value": round(B * nx / dtx, 2), "unit": "pairs/s", "steps": nx, "ms_per_step": round(1e3 * dtx / nx, 4),
-                          "dtype": "f32 activations / weights split into 3 x bf16 for the stage-1 32->32 Conv3D MFMAs, f32 accumulate",
-                          "k_conv3d_mid16x_avg_launch_us": round(x_us, 2), "max_abs_vs_exact_per_stage": diff,
-                          "what": "option mid16_form = 1: not bit-exact against the oracle chain (float32-level accuracy, gated by "
+                          "dtype": "f32 activations / weights split into 3 x bf16 for the MFMAs of the stage-1 32->32 Conv3D layers "
+                                   "and of refinement2[0], f32 accumulate",
+                          "k_conv3d_mid16x_avg_launch_us": round(x_us, 2), "k_ref_conv64x_avg_launch_us": round(x64_us, 2),
+                          "max_abs_vs_exact_per_stage": diff,
+                          "what": "options mid16_form = conv64_form = 1: not bit-exact against the oracle chain (float32-level accuracy, gated by "
                                   "the float64 noise-floor tests); an opt-in numerics mode, never the headline"}
         finally:
             model.set_option("mid16_form", 0)
+            model.set_option("conv64_form", 0)
     if grouped:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -453,8 +460,12 @@ def main():
     roof = None
     if mid:
         achieved = flop_per_launch / (mid["avg_us"] * 1e-6) / 1e12
-        roof = {"bound": "mfma", "kernel": "k_conv3d_mid16<32,3,4>", "achieved": round(achieved, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        # with --opt mid16_form=1 (experiments only) the class runs k_conv3d_mid16x: six bf16 MFMAs per float32 product,
+        # so the ceiling for the same algorithmic FLOPs is the dense bf16 peak / 6
+        split = model.get_option("mid16_form") == 1
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS
+        roof = {"bound": "mfma", "kernel": "k_conv3d_mid16x<3,4> (split-bf16, NOT the oracle chain)" if split else "k_conv3d_mid16<32,3,4>",
+                "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": None, "flop_per_launch": flop_per_launch, "avg_launch_us": round(mid["avg_us"], 2),
                 "timed_launches": int(mid_n), "timed_every_nth_step": sample_every, "pairs_per_launch": pairs_per_launch}
     # the whole step against the same fp32-MFMA peak: algorithmic GF of a forward x pairs / step time.  This, not `frac`,
@@ -558,11 +569,15 @@ def main():
                              "max_abs_gpu_vs_literal_fp32": [round(float((npred[s] - n32[s]).abs().max()), 6) for s in range(4)]}
 
     pairs = world * B * args.steps
+    dtype_name = "f32 (fp16-rounded features)" if args.feature_fp16 else "f32"
+    if model.get_option("mid16_form") == 1 or model.get_option("conv64_form") == 1:
+        # experiments only (--opt): the opt-in numerics mode, float32-level accuracy but not the oracle's bits
+        dtype_name += " with split-bf16 MFMA operands (3 x bf16 per f32, f32 accumulate; not bit-exact against the oracle)"
     out = {
         "metric": "stereo pairs/sec @256x512 maxdisp=192 (stage-4)",
         "value": round(pairs / elapsed, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "spinup_s": round(spun_s, 3), "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp16-rounded features)" if args.feature_fp16 else "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": (f"BASELINE config 2: batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[24,5,5], all 4 stages"
                                 if (H, W, args.maxdisp0) == (256, 512, 24) else
                                 f"batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[{args.maxdisp0},5,5], all 4 stages"),

@@ -281,7 +281,7 @@ struct Net2dOffsets {
     size_t r1_first[2];
     struct D { size_t s, t, dw, pw; };
     D r1[2][4], r2[4];
-    size_t r2f_s, r2f_t, r2f_w, r2_last;
+    size_t r2f_s, r2f_t, r2f_w, r2f_wx, r2_last;
 };
 
 static bool have_all_2d(const lws_ctx *h)
@@ -379,6 +379,9 @@ static void build_net2d(const lws_ctx *h, std::vector<float> &slab, Net2dOffsets
         std::vector<float> wp(10 * 4 * 2 * 64 * 4, 0.0f);   // 9 taps + one all-zero tap (prefetch without bounds check)
         pack_conv2d_mfma(h->host.at("refinement2.0.2.weight").data(), 64, 9, wp.data());   // [32][64][3][3]
         o.r2f_w = sb.put(wp);
+        std::vector<float> wx(packed_conv64x_floats(), 0.0f);
+        pack_conv64_bf16x3(h->host.at("refinement2.0.2.weight").data(), wx.data());
+        o.r2f_wx = sb.put(wx);
     }
     for (int b = 0; b < 4; ++b) pack_dws(h, sb, "refinement2." + std::to_string(b + 1), o.r2[b]);
     {
@@ -416,6 +419,7 @@ static void bind_net2d(lws_ctx *h, const Net2dOffsets &o)
     n.r2_first.bn_s = h->params + o.r2f_s;
     n.r2_first.bn_t = h->params + o.r2f_t;
     n.r2_first.w = h->params + o.r2f_w;
+    n.r2_first.wx = h->params + o.r2f_wx;
     for (int b = 0; b < 4; ++b) bind_dws(n.r2[b], o.r2[b], 8 >> b);                 // dilation 8,4,2,1 (submodules.py:316)
     n.r2_last = h->params + o.r2_last;
 }
@@ -819,6 +823,7 @@ static void apply_options(lws_ctx *h)
         h->stage[i].dfast = h->opt.conv3d_order;
         h->stage[i].mid16_form = h->opt.mid16_form;
     }
+    h->net2d.r2_first.form = h->opt.conv64_form;
 }
 
 static int *option_slot(lws_ctx *h, const char *name)
@@ -831,6 +836,7 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"side_streams", &h->opt.side_streams},
                                                      {"conv3d_order", &h->opt.conv3d_order},
                                                      {"mid16_form", &h->opt.mid16_form},
+                                                     {"conv64_form", &h->opt.conv64_form},
                                                      {"ref_chunk_mb", &h->opt.ref_chunk_mb},
                                                      {"device", &h->device},
                                                      {"mid8_form", &h->opt.mid8_form}};

@@ -136,6 +136,8 @@ struct RefDws {
 struct RefConv64 {
     float *bn_s = nullptr, *bn_t = nullptr;   // [64]
     float *w = nullptr;                       // MFMA A fragments [tap][qq][mt][lane][4]
+    float *wx = nullptr;                      // split-bf16 A fragments [step][mt][variant][lane][8 bf16] (k_ref_conv64x)
+    int form = 0;                             // 0 = k_ref_conv64 (f32 MFMA, the oracle's chain), 1 = k_ref_conv64x (not bit-exact)
 };
 
 struct Net2d {
@@ -166,6 +168,7 @@ struct lws_ctx {
         int mid8_form = 1;         // 8 -> 8 Conv3D layers: 0 = k_conv3d_mid8 (16x16x4), 1 = k_conv3d_mid8q (4x4x1_16B, no zero padding)
         int side_streams = 1;      // 0: no handle-owned side streams, the whole forward on the caller's stream (lws_pool workers)
         int mid16_form = 0;        // 1: stage-1 middle Conv3D layers on split-bf16 MFMA (k_conv3d_mid16x): float32-level accuracy, NOT bit-exact
+        int conv64_form = 0;       // 1: refinement2[0] (64 -> 32, dilation 8) on split-bf16 MFMA (k_ref_conv64x): NOT bit-exact
         int conv3d_order = 1;      // tile order of the Conv3D stacks: 0 = x fastest, 1 = d fastest (halo planes shared inside an XCD's L2)
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
     } opt;
@@ -240,6 +243,8 @@ int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, fl
                       hipStream_t st);
 int launch_ref_last(const float *in, const float *w, const float *pred3, float *out, int B, int H, int W, hipStream_t st);
 void pack_conv2d_mfma(const float *w, int cin, int ktaps, float *out);
+size_t packed_conv64x_floats();
+void pack_conv64_bf16x3(const float *w, float *out);   // [32][64][3][3] -> k_ref_conv64x fragments
 
 bool conv3d_last_can_fuse(const Stage3d &s, int D);
 int launch_conv3d_last_softargmin(const Stage3d &s, const float *act_in, const float *cost_skip, float *cost_out,

@@ -957,6 +957,166 @@ __global__ __launch_bounds__(64 * NW) void k_ref_conv64(const float *__restrict_
 }
 
 // =============================================================================================
+// refinement2[0], split-bf16 form (k_ref_conv64x; option "conv64_form" = 1, NOT the default and never what bench.py's
+// headline measures: like k_conv3d_mid16x it is not bit-exact against the oracle chain, see lws_conv3d.hip).
+// Same tile and interface as k_ref_conv64.  The BN + ReLU'd halo pixels are split into hi / mid / lo bf16 while they are
+// staged ([tensor][halo pixel][variant][32 channels] bf16, 208-byte pixel stride); one step = (tap, tensor) contracts 32
+// input channels with six v_mfma_f32_16x16x32_bf16 per accumulator, smallest cross terms first.  Weights are pre-split on
+// the host into A fragments [step][mt][variant][lane][8] (pack_conv64_bf16x3) and streamed two steps ahead through a
+// three-slot register ring; activation fragments are double-buffered by step parity.
+// =============================================================================================
+constexpr int C64X_VSB = 208;                        // LDS pixel stride in bytes: 3 variants x 64 B + 16 B
+constexpr int C64X_STEP_U4 = 2 * 3 * 64;             // uint4 per (tap, tensor) step of the packed weights
+
+template <int TY, int NW>
+struct Conv64xCfg {
+    static constexpr int HY = TY + 2, NPX = HY * RH_X, RW = TY / NW, NT = 64 * NW;
+    static constexpr int ITEMS = 2 * NPX * 2, SITER = (ITEMS + NT - 1) / NT;
+    static constexpr int LDS_BYTES = 2 * NPX * C64X_VSB;
+    static_assert(TY % NW == 0 && RW >= 1 && RW <= 4, "rows must split evenly over the waves");
+};
+
+template <int TY, int NW>
+__global__ __launch_bounds__(64 * NW) void k_ref_conv64x(const float *__restrict__ inL, const float *__restrict__ inD,
+                                                     const float *__restrict__ bn_s, const float *__restrict__ bn_t,   // [64]
+                                                     const uint4 *__restrict__ wpk,   // [20][2][3][64] x 8 bf16
+                                                     float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt)
+{
+    using Cfg = Conv64xCfg<TY, NW>;
+    constexpr int NPX = Cfg::NPX, RW = Cfg::RW, NT = Cfg::NT, SITER = Cfg::SITER, VSB = C64X_VSB;
+    extern __shared__ __attribute__((aligned(16))) float lds64x[];
+    unsigned char *ldsb = reinterpret_cast<unsigned char *>(lds64x);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const RefTile t = ref_tile(dil, nbx, nby, TY);
+    const int n = lane & 15, g = lane >> 4;
+
+    // stage: item = (tensor, halo pixel, 16-channel group) = 64 B of float32 -> BN + ReLU -> 3 x 32 B of bf16
+    {
+        float4 c[SITER][4];
+        bool okv[SITER];
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * NT;
+            const int q = it & 1, hp = (it >> 1) % NPX, ten = (it >> 1) / NPX;
+            const int hy = hp / RH_X, hx = hp % RH_X;
+            const int gy = t.Y0 + (hy - 1) * dil, gx = t.X0 + (hx - 1) * dil;
+            okv[i] = it < Cfg::ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float *base = (ten == 1 && it < Cfg::ITEMS ? inD : inL) + (int64_t)t.b * H * W * 32;
+            const float4 *src = reinterpret_cast<const float4 *>(base + (okv[i] ? ((int64_t)gy * W + gx) * 32 + q * 16 : 0));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[i][k] = src[k];
+        }
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int it = tid + i * NT;
+            if (it < Cfg::ITEMS) {
+                const int q = it & 1, pix = it >> 1, ten = pix / NPX;     // pix = ten * NPX + hp: the images are back to back
+                const float4 *sp = reinterpret_cast<const float4 *>(bn_s + ten * 32 + q * 16);
+                const float4 *tp = reinterpret_cast<const float4 *>(bn_t + ten * 32 + q * 16);
+                uint32_t pk[3][8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 v = c[i][k], sc = sp[k], tt = tp[k];
+                    float xs[4] = {bn_relu2(v.x, sc.x, tt.x), bn_relu2(v.y, sc.y, tt.y), bn_relu2(v.z, sc.z, tt.z),
+                                   bn_relu2(v.w, sc.w, tt.w)};
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2)
+                        split_bf16x3_pair(okv[i] ? xs[e] : 0.f, okv[i] ? xs[e + 1] : 0.f, pk[0][2 * k + e / 2],
+                                          pk[1][2 * k + e / 2], pk[2][2 * k + e / 2]);
+                }
+#pragma unroll
+                for (int v3 = 0; v3 < 3; ++v3) {
+                    uint4 *dst = reinterpret_cast<uint4 *>(ldsb + pix * VSB + v3 * 64 + q * 32);
+                    dst[0] = make_uint4(pk[v3][0], pk[v3][1], pk[v3][2], pk[v3][3]);
+                    dst[1] = make_uint4(pk[v3][4], pk[v3][5], pk[v3][6], pk[v3][7]);
+                }
+            }
+        }
+    }
+    const uint4 *wp = wpk + lane;
+    uint4 wa[3][2][3];                              // ring over steps: step s lives in slot s % 3 (6 steps per kh iteration)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int v3 = 0; v3 < 3; ++v3) {
+            wa[0][mt][v3] = wp[(mt * 3 + v3) * 64];
+            wa[1][mt][v3] = wp[C64X_STEP_U4 + (mt * 3 + v3) * 64];
+        }
+    __syncthreads();
+
+    floatx4 acc[RW][2];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[r][mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    const unsigned char *rptr[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) rptr[r] = ldsb + ((RW * wave + r) * RH_X + n) * VSB + g * 16;
+    auto as_frag = [](const uint4 &u) {
+        union { uint4 u4; bf16x8 v; } cv;
+        cv.u4 = u;
+        return cv.v;
+    };
+    uint4 bb[2][RW][3];
+    auto load_b = [&](uint4 (&dst)[RW][3], int off) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int v3 = 0; v3 < 3; ++v3) dst[r][v3] = *reinterpret_cast<const uint4 *>(rptr[r] + off + v3 * 64);
+    };
+    load_b(bb[0], 0);
+
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+        const int base = kh * RH_X * VSB;
+        const int base_n = (kh < 2 ? kh + 1 : 2) * RH_X * VSB;          // (clamped: the last prefetch is unused)
+        const uint4 *wrow = wp + (size_t)(kh * 6) * C64X_STEP_U4;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {                                   // s = 2 kw + tensor
+            const int kw = s >> 1, cb = s & 1, nb = cb ^ 1;
+            // prefetch: the next step's activation fragments, and the weights of step + 2 into the slot of step - 1
+            const int sn = s + 1;
+            load_b(bb[nb], (sn < 6 ? base + (sn >> 1) * VSB : base_n) + (sn & 1) * NPX * VSB);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int v3 = 0; v3 < 3; ++v3) wa[(s + 2) % 3][mt][v3] = wrow[(size_t)(s + 2) * C64X_STEP_U4 + (mt * 3 + v3) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            (void)kw;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const bf16x8 bh = as_frag(bb[cb][r][0]), bm = as_frag(bb[cb][r][1]), bl = as_frag(bb[cb][r][2]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const bf16x8 ah = as_frag(wa[s % 3][mt][0]), am = as_frag(wa[s % 3][mt][1]), al = as_frag(wa[s % 3][mt][2]);
+                    floatx4 a = acc[r][mt];                 // smallest terms first
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, a, 0, 0, 0);
+                    acc[r][mt] = a;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float *outb = out + (int64_t)t.b * H * W * 32;
+    const int gx = t.X0 + n * dil;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int gy = t.Y0 + (RW * wave + r) * dil;
+        if (gy < H && gx < W) {
+            float *o = outb + ((int64_t)gy * W + gx) * 32;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                store_act4(o + mt * 16 + 4 * g, make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]), wt);
+        }
+    }
+}
+
+// =============================================================================================
 // refinement2[5] + skip (submodules.py:318-325, models.py:161-162): Conv 3x3 pad 1, 32 -> 1, plus pred3.
 // =============================================================================================
 constexpr int LAST_TY = 8, LAST_TX = 32, LAST_HY = LAST_TY + 2, LAST_HX = LAST_TX + 2, LAST_NPX = LAST_HY * LAST_HX;
@@ -1067,6 +1227,20 @@ int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, fl
                       hipStream_t st)
 {
     const int dil = 8;
+    if (l.form == 1) {
+        // split-bf16 form: 8-row tiles, 4 waves x 2 rows, 73 KB of LDS (2 workgroups per CU)
+        using Cfg = Conv64xCfg<8, 4>;
+        static std::atomic<uint64_t> attr_done{0};
+        const int rc_ = ensure_dyn_lds(attr_done, reinterpret_cast<const void *>(&k_ref_conv64x<8, 4>), Cfg::LDS_BYTES);
+        if (rc_ != LWS_OK) return rc_;
+        const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, 8 * dil);
+        dim3 grid(nbx * nby * dil * dil * B), block(Cfg::NT);
+        hipLaunchKernelGGL((k_ref_conv64x<8, 4>), grid, block, Cfg::LDS_BYTES, st, inL, inD, l.bn_s, l.bn_t,
+                           reinterpret_cast<const uint4 *>(l.wx), out, H, W, dil, nbx, nby,
+                           use_wt_stores((size_t)B * H * W * 128));
+        LWS_LAUNCH_CHECK();
+        return LWS_OK;
+    }
 #define LWS_C64(TYv, NWv)                                                                                          \
     {                                                                                                               \
         const int nbx = cdiv(W, RT_X * dil), nby = cdiv(H, TYv * dil);                                              \
@@ -1105,6 +1279,23 @@ void pack_conv2d_mfma(const float *w, int cin, int ktaps, float *out)
                         const int co = 16 * mt + m, ci = 16 * q + 4 * j + g;
                         out[((((size_t)tap * Q + q) * 2 + mt) * 64 + lane) * 4 + j] = w[((size_t)co * cin + ci) * ktaps + tap];
                     }
+}
+
+// k_ref_conv64x: lane l of (step = 2 tap + tensor, mt, variant) holds W[16 mt + (l & 15)][32 tensor + 8 (l >> 4) + j][tap],
+// j = 0..7, as bf16 bits; 18 steps + two all-zero steps (the two-steps-ahead prefetch needs no bounds check)
+size_t packed_conv64x_floats() { return (size_t)20 * 2 * 3 * 64 * 4; }
+void pack_conv64_bf16x3(const float *w, float *out)
+{
+    uint16_t *ox = reinterpret_cast<uint16_t *>(out);
+    for (int step = 0; step < 20; ++step)
+        for (int mt = 0; mt < 2; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int tap = step >> 1, co = 16 * mt + (lane & 15), ci = 32 * (step & 1) + 8 * (lane >> 4) + j;
+                    uint32_t v[3] = {0, 0, 0};
+                    if (step < 18) split_bf16x3(w[((size_t)co * 64 + ci) * 9 + tap], v[0], v[1], v[2]);
+                    for (int t = 0; t < 3; ++t) ox[((((size_t)step * 2 + mt) * 3 + t) * 64 + lane) * 8 + j] = (uint16_t)v[t];
+                }
 }
 
 }  // namespace lws

@@ -323,51 +323,6 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
 // while the halo tile is staged into LDS ([voxel][variant hi/mid/lo][32 channels] bf16, 208-byte voxel stride), the
 // weights are pre-split on the host into A fragments [tap][mt][variant][lane][8] and streamed one tap ahead.
 // =============================================================================================
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
-// float32 -> bf16 bits, round to nearest even (finite values; the activations are BN + ReLU outputs)
-__host__ __device__ __forceinline__ uint32_t f2bf_bits(float x)
-{
-    union { float f; uint32_t u; } v;
-    v.f = x;
-    return (v.u + 0x7FFFu + ((v.u >> 16) & 1u)) >> 16;
-}
-__host__ __device__ __forceinline__ float bf_bits2f(uint32_t h)
-{
-    union { float f; uint32_t u; } v;
-    v.u = h << 16;
-    return v.f;
-}
-// x -> (hi, mid, lo) bf16 bit patterns; every subtraction is exact in float32
-__host__ __device__ __forceinline__ void split_bf16x3(float x, uint32_t &hi, uint32_t &mid, uint32_t &lo)
-{
-    hi = f2bf_bits(x);
-    const float r1 = x - bf_bits2f(hi);
-    mid = f2bf_bits(r1);
-    const float r2 = r1 - bf_bits2f(mid);
-    lo = f2bf_bits(r2);
-}
-
-// device form for two values at once: v_cvt_pk_bf16_f32 (round to nearest even, the same rounding as f2bf_bits) -- 11
-// instructions per pair instead of ~40 for the bit arithmetic; result dwords hold (x0's, x1's) bf16 in (low, high) halves
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b)
-{
-    typedef float f2_ __attribute__((ext_vector_type(2)));
-    typedef __bf16 b2_ __attribute__((ext_vector_type(2)));
-    const f2_ v = {a, b};
-    const b2_ r = __builtin_convertvector(v, b2_);
-    return __builtin_bit_cast(uint32_t, r);
-}
-__device__ __forceinline__ void split_bf16x3_pair(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l)
-{
-    h = pack_bf16x2(x0, x1);
-    float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = pack_bf16x2(r0, r1);
-    r0 = r0 - __uint_as_float(m << 16);
-    r1 = r1 - __uint_as_float(m & 0xffff0000u);
-    l = pack_bf16x2(r0, r1);
-}
-
 template <int TD, int TY>
 struct Mid16xCfg {
     static constexpr int C3 = 32, MT = 2, NW = 4, NT = 256;

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--size", default="256x512")
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--opt", action="append", default=[], help="name=value launch-plan option (lws_set_option)")
     a = ap.parse_args()
     H, W = [int(v) for v in a.size.split("x")]
     from lwsnet_amd import _lib, ops
@@ -26,6 +27,8 @@ def main():
     dev = torch.device("cuda:0")
     m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
     lib = _lib.load()
+    for o in a.opt:
+        m.set_option(o.split("=")[0], int(o.split("=")[1]))
     left = torch.randn((a.batch, 3, H, W), device=dev)
     p3 = torch.rand((a.batch, 1, H, W), device=dev) * 100
     outs = {}

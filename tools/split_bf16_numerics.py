@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Numerics account of option mid16_form = 1 (k_conv3d_mid16x, split-bf16 MFMA in the stage-1 32 -> 32 Conv3D layers):
+"""Numerics account of options mid16_form = conv64_form = 1 (k_conv3d_mid16x / k_ref_conv64x: split-bf16 MFMA in the stage-1
+32 -> 32 Conv3D layers and in refinement2[0]; --only mid16_form | conv64_form for one of them):
 per stage, max and mean |result - float64 literal oracle| of (a) the exact HIP build (the oracle's float32 chain bit for bit),
 (b) the split-bf16 build, (c) the float32 literal oracle, over several seeded pairs.  VERDICT r2 item 8: the split form is
 acceptable only if it is no further from float64 than the float32 chain is.   python tools/split_bf16_numerics.py [--pairs N]"""
@@ -11,6 +12,7 @@ import torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=6)
 ap.add_argument("--size", default="64x256")
+ap.add_argument("--only", default="", help="mid16_form or conv64_form: switch only this option (default: both)")
 a = ap.parse_args()
 H, W = [int(v) for v in a.size.split("x")]
 from lwsnet_amd.models import LWSNet
@@ -30,9 +32,12 @@ for i in range(a.pairs):
     l, r = l[None], r[None]
     ref64 = lws_oracle.forward(l, r, sd, (24, 5, 5), dtype=torch.float64)
     ref32 = lws_oracle.forward(l, r, sd, (24, 5, 5))
-    m.set_option("mid16_form", 0)
+    names = [a.only] if a.only else ["mid16_form", "conv64_form"]
+    for o in names:
+        m.set_option(o, 0)
     exact = [p.cpu().double() for p in m(l, r)]
-    m.set_option("mid16_form", 1)
+    for o in names:
+        m.set_option(o, 1)
     split = [p.cpu().double() for p in m(l, r)]
     for name, res in (("exact HIP", exact), ("split-bf16 HIP", split), ("float32 literal oracle", [p.double() for p in ref32])):
         e = [(res[s] - ref64[s]).abs() for s in range(4)]
