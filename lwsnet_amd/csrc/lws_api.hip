@@ -848,6 +848,15 @@ static int *option_slot(lws_ctx *h, const char *name)
 int lws_set_option(lws_handle h, const char *name, int value)
 {
     LWS_CHECK_ARG(h && name, "lws_set_option: null argument");
+    if (strcmp(name, "split_bf16") == 0) {
+        // the opt-in numerics mode as one switch: every MFMA convolution that has a split-bf16 form (NOT bit-exact)
+        LWS_CHECK_ARG(value == 0 || value == 1, "lws_set_option: split_bf16 must be 0 or 1 (got %d)", value);
+        h->opt.mid16_form = value;
+        h->opt.conv64_form = value;
+        h->opt.mid8_form = value ? 2 : 1;
+        apply_options(h);
+        return LWS_OK;
+    }
     int *slot = option_slot(h, name);
     LWS_CHECK_ARG(slot != nullptr, "lws_set_option: unknown option '%s'", name);
     if (strcmp(name, "left_at") == 0)
@@ -862,6 +871,8 @@ int lws_set_option(lws_handle h, const char *name, int value)
                       "lws_set_option: the device of a handle can only be changed before lws_finalize / lws_reserve "
                       "have allocated on device %d", h->device);
     }
+    else if (strcmp(name, "mid8_form") == 0)
+        LWS_CHECK_ARG(value >= 0 && value <= 2, "lws_set_option: mid8_form must be 0, 1 or 2 (got %d)", value);
     else
         LWS_CHECK_ARG(value == 0 || value == 1, "lws_set_option: %s must be 0 or 1 (got %d)", name, value);
     *slot = value;
@@ -872,6 +883,10 @@ int lws_set_option(lws_handle h, const char *name, int value)
 int lws_get_option(lws_handle h, const char *name, int *value)
 {
     LWS_CHECK_ARG(h && name && value, "lws_get_option: null argument");
+    if (strcmp(name, "split_bf16") == 0) {
+        *value = (h->opt.mid16_form == 1 && h->opt.conv64_form == 1 && h->opt.mid8_form == 2) ? 1 : 0;
+        return LWS_OK;
+    }
     int *slot = option_slot(h, name);
     LWS_CHECK_ARG(slot != nullptr, "lws_get_option: unknown option '%s'", name);
     *value = *slot;

@@ -668,6 +668,182 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ i
 }
 
 // =============================================================================================
+// Middle layers, C3 == 8, split-bf16 form (k_conv3d_mid8x; option "mid8_form" = 2, NOT the default and never what bench.py's
+// headline measures: not bit-exact against the oracle chain, see k_conv3d_mid16x).
+// The parity-row tile of k_conv3d_mid8 -- row i = 8 xpar + cout, column n = voxel pair, output x = x0 + 2 n + xpar -- with
+// K = 32 = 4 x-offsets t x 8 input channels: ONE v_mfma_f32_16x16x32_bf16 contracts a whole (kd, kh) row of taps, lane
+// (n, g) supplying the 8 channels of voxel x0 + 2 n + g - 1 (one ds_read_b128 per variant) against
+// W[cout][cin][kd][kh][g - xpar] (zero where g - xpar is outside 0..2).  9 steps x 6 cross products = 54 MFMAs of 16 cycles
+// per row of 32 outputs, against 216 x 10 cycles on the 4x4x1 form.  LDS: three variant planes [voxel][8 x bf16] with the
+// 16-byte voxel slots XOR-swizzled by bit 4 of the voxel index, so that the 16 lanes of a ds_read_b128 (voxels c, c + 2, ...,
+// c + 30) cover 16 different slots mod 256 B for every c.  Weights pre-split on the host ([step][variant][lane][8]) and
+// streamed two steps ahead; staging in two phases and epilogue as k_conv3d_mid8.
+// =============================================================================================
+template <int TD, int TY>
+struct Mid8xCfg {
+    static constexpr int NW = 4, NT = 256;
+    static constexpr int ROWS = TD * TY, RW = ROWS / NW;
+    static constexpr int HD = TD + 2, HY = TY + 2, HX = 34;
+    static constexpr int NVOX = HD * HY * HX;
+    static constexpr int PLANE = ((NVOX + 15) & ~15) * 16;      // bytes per variant plane (whole 16-voxel swizzle groups)
+    static constexpr int LDS_BYTES = 3 * PLANE;
+    static constexpr int SITER = (NVOX + NT - 1) / NT;           // item = voxel (8 channels, 32 B of float32)
+    static constexpr int STEP_U4 = 3 * 64;                       // uint4 per (kd, kh) step of the packed weights
+    static_assert(ROWS % NW == 0, "rows must split evenly over the waves");
+};
+constexpr size_t MID8X_PACK_FLOATS = (size_t)11 * 3 * 64 * 4;   // 9 steps + two all-zero steps
+
+__device__ __forceinline__ int mid8x_slot(int v) { return (v ^ ((v >> 4) & 1)) * 16; }
+
+template <int TD, int TY>
+__global__ __launch_bounds__(256) void k_conv3d_mid8x(const float *__restrict__ in,      // [B,D,h,w,8]
+                                                      const uint4 *__restrict__ wpk,     // [11][3][64] x 8 bf16
+                                                      const float *__restrict__ bn_s,    // next layer BN [8]
+                                                      const float *__restrict__ bn_t,
+                                                      float *__restrict__ out, int D, int h, int w,
+                                                      int tiles_x, int tiles_y, int tord)
+{
+    using Cfg = Mid8xCfg<TD, TY>;
+    constexpr int RW = Cfg::RW, HY = Cfg::HY, HX = Cfg::HX, NT = Cfg::NT, SITER = Cfg::SITER, PLANE = Cfg::PLANE;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned char *ldsb = reinterpret_cast<unsigned char *>(lds);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    int tx, ty, td;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
+    const int b = blockIdx.y;
+    const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
+    const float *inb = in + (int64_t)b * D * h * w * 8;
+
+    float4 c[SITER][2];
+    bool okv[SITER];
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int v = tid + i * NT;
+        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
+        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        okv[i] = v < Cfg::NVOX && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        const float4 *src = reinterpret_cast<const float4 *>(inb + (okv[i] ? (((int64_t)gd * h + gy) * w + gx) * 8 : 0));
+        c[i][0] = src[0];
+        c[i][1] = src[1];
+    }
+    const int xpar = g >> 1, cb8 = 4 * (g & 1);
+    const float4 es8 = *reinterpret_cast<const float4 *>(bn_s + cb8);
+    const float4 et8 = *reinterpret_cast<const float4 *>(bn_t + cb8);
+    const uint4 *wp = wpk + lane;
+    uint4 wa[3][3];                                 // ring over kh: step (kd, kh) lives in slot kh; the stream runs TWO steps ahead
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        wa[0][t] = wp[t * 64];
+        wa[1][t] = wp[Cfg::STEP_U4 + t * 64];
+    }
+    constexpr int P1 = (TD * HY * HX + NT - 1) / NT < SITER ? (TD * HY * HX + NT - 1) / NT : SITER;
+    auto stage_write = [&](int i) {
+        const int v = tid + i * NT;
+        if (v < Cfg::NVOX) {
+            uint32_t pk[3][4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float xs[4] = {c[i][k].x, c[i][k].y, c[i][k].z, c[i][k].w};
+#pragma unroll
+                for (int e = 0; e < 4; e += 2)
+                    split_bf16x3_pair(okv[i] ? xs[e] : 0.f, okv[i] ? xs[e + 1] : 0.f, pk[0][2 * k + e / 2], pk[1][2 * k + e / 2],
+                                      pk[2][2 * k + e / 2]);
+            }
+            unsigned char *dst = ldsb + mid8x_slot(v);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                *reinterpret_cast<uint4 *>(dst + t * PLANE) = make_uint4(pk[t][0], pk[t][1], pk[t][2], pk[t][3]);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < P1; ++i) stage_write(i);
+    __syncthreads();
+
+    floatx4 acc[RW];
+    int rbase[RW];                                  // halo voxel (rd, ry, 2 n + g) of this lane's row
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        acc[r] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        const int row = wave * RW + r;
+        rbase[r] = (row / TY * HY + row % TY) * HX + 2 * n + g;
+    }
+    auto as_frag = [](const uint4 &u) {
+        union { uint4 u4; bf16x8 v; } cv;
+        cv.u4 = u;
+        return cv.v;
+    };
+    uint4 bb[2][RW][3];
+    auto load_b = [&](uint4 (&dst)[RW][3], int off) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const unsigned char *p = ldsb + mid8x_slot(rbase[r] + off);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) dst[r][t] = *reinterpret_cast<const uint4 *>(p + t * PLANE);
+        }
+    };
+    load_b(bb[0], 0);
+
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd) {
+        const int base = kd * HY * HX;
+        const int base_n = (kd < 2 ? kd + 1 : 2) * HY * HX;           // (clamped: the prefetch of the last iteration is unused)
+        const uint4 *wrow = wp + (size_t)(kd * 3) * Cfg::STEP_U4;
+        if (P1 < SITER && kd == 1) {
+            // phase 2 of the staging (halo planes TD, TD + 1); the fragments prefetched at the end of kd = 0 may predate it
+#pragma unroll
+            for (int i = P1; i < SITER; ++i) stage_write(i);
+            __syncthreads();
+            load_b(bb[0], base);
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int cb = kh & 1, nb = cb ^ 1;
+            load_b(bb[nb], kh < 2 ? base + (kh + 1) * HX : base_n);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) wa[(kh + 2) % 3][t] = wrow[(size_t)(kh + 2) * Cfg::STEP_U4 + t * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 ah = as_frag(wa[kh][0]), am = as_frag(wa[kh][1]), al = as_frag(wa[kh][2]);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const bf16x8 bh = as_frag(bb[cb][r][0]), bm = as_frag(bb[cb][r][1]), bl = as_frag(bb[cb][r][2]);
+                floatx4 a = acc[r];                     // smallest terms first
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, a, 0, 0, 0);
+                acc[r] = a;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bb[0][r][t] = bb[1][r][t];
+    }
+
+    // ---- epilogue (as k_conv3d_mid8): row i = 4*(lane>>4) + reg -> xpar = (lane>>4)>>1, cout = 4*((lane>>4)&1) + reg
+    float *outb = out + (int64_t)b * D * h * w * 8;
+    const int gx = x0 + 2 * n + xpar;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = wave * RW + r;
+        const int gd = d0 + row / TY, gy = y0 + row % TY;
+        if (gd < D && gy < h && gx < w) {
+            float4 v;
+            v.x = bn_relu(acc[r][0], es8.x, et8.x);
+            v.y = bn_relu(acc[r][1], es8.y, et8.y);
+            v.z = bn_relu(acc[r][2], es8.z, et8.z);
+            v.w = bn_relu(acc[r][3], es8.w, et8.w);
+            store_act4(outb + (((int64_t)gd * h + gy) * w + gx) * 8 + cb8, v, 0);
+        }
+    }
+}
+
+// =============================================================================================
 // Middle layers, C3 == 8, on v_mfma_f32_4x4x1_16B_f32 (k_conv3d_mid8q, option "mid8_form" = 1).
 //
 // The 16x16x4 form above pays 25 % of every instruction for structural zeros (two output positions share a 16-row
@@ -1171,7 +1347,7 @@ __global__ __launch_bounds__((LastCfg<C3, TD, TY, TX, FUSE>::NT)) void k_conv3d_
 constexpr size_t MID8_PACK = 72 * 64;      // k_conv3d_mid8's fragments; k_conv3d_mid8q's 28 x 64 follow
 size_t packed_mid_weight_floats(int c3)
 {
-    if (c3 == 8) return MID8_PACK + 28 * 64;
+    if (c3 == 8) return MID8_PACK + 28 * 64 + MID8X_PACK_FLOATS;   // k_conv3d_mid8's, k_conv3d_mid8q's, k_conv3d_mid8x's
     // 27 taps + two all-zero taps (branch-free two-taps-ahead prefetch in k_conv3d_mid16); C3 == 32: + the split-bf16
     // fragments of k_conv3d_mid16x, 29 taps (two all-zero) x 2 cout tiles x 3 variants x 64 lanes x 8 bf16 = 16 B each
     return (size_t)29 * c3 * c3 + (c3 == 32 ? (size_t)29 * 2 * 3 * 64 * 4 : 0);
@@ -1203,6 +1379,17 @@ void pack_mid_weights(const float *w, int c3, float *out)
                 const int k = lane >> 2, i = lane & 3, cin = k >> 1, cg = k & 1;
                 oq[((tap >> 2) * 64 + lane) * 4 + (tap & 3)] = tap < 27 ? w[((4 * cg + i) * 8 + cin) * 27 + tap] : 0.0f;
             }
+        // k_conv3d_mid8x: lane l of (step = 3 kd + kh, variant) holds W[l & 7][cin = j][kd][kh][kw = (l >> 4) - ((l >> 3) & 1)],
+        // j = 0..7, as bf16 bits (zero where kw is outside 0..2); two all-zero steps close the stream
+        uint16_t *ox = reinterpret_cast<uint16_t *>(out + MID8_PACK + 28 * 64);
+        for (int step = 0; step < 11; ++step)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int i = lane & 15, xpar = i >> 3, cout = i & 7, kw = (lane >> 4) - xpar;
+                    uint32_t v[3] = {0, 0, 0};
+                    if (step < 9 && kw >= 0 && kw <= 2) split_bf16x3(w[(cout * 8 + j) * 27 + step * 3 + kw], v[0], v[1], v[2]);
+                    for (int t = 0; t < 3; ++t) ox[(((size_t)step * 3 + t) * 64 + lane) * 8 + j] = (uint16_t)v[t];
+                }
         return;
     }
     const int Q = c3 / 16, MT = c3 / 16;
@@ -1386,6 +1573,22 @@ static int mid8q_launch(const Stage3d &s, int layer, const float *in, float *out
     return LWS_OK;
 }
 
+template <int TD, int TY>
+static int mid8x_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w, hipStream_t st)
+{
+    using Cfg = Mid8xCfg<TD, TY>;
+    static std::atomic<uint64_t> attr_done{0};
+    const int rc_ = ensure_dyn_lds(attr_done, reinterpret_cast<const void *>(&k_conv3d_mid8x<TD, TY>), Cfg::LDS_BYTES);
+    if (rc_) return rc_;
+    const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
+    dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
+    hipLaunchKernelGGL((k_conv3d_mid8x<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in,
+                       reinterpret_cast<const uint4 *>(s.layers[layer].w + MID8_PACK + 28 * 64), s.layers[layer + 1].bn_s,
+                       s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
+    LWS_LAUNCH_CHECK();
+    return LWS_OK;
+}
+
 // layer = 1 .. layers_3d (the C3 -> C3 convolutions)
 int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *act_out, int B, int D, int h,
                       int w, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
@@ -1398,7 +1601,12 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
             // 8.7 vs 7.8 at B = 1, 13.4 vs 12.2 at B = 2, 32.5 vs 29.0 at B = 8; stage 3 (9 x 128 x 256) 17.6 vs 15.9, 30.0 vs 28.8,
             // 105.0 vs 94.8; 8 x 368x1232: 102 vs 85 and 369 vs 328.  (Without the two-phase staging the 4x4x1 form lost at
             // 8 x 9x64x128 and 2 x 9x128x256: 34.5 and 33.3 us.)
-            if (s.mid8_form == 1) {
+            // split-bf16 (NOT bit-exact).  Measured r03 (tools/sbench.py, us per launch, 4x4x1 -> split): 8 x 9x128x256 81.8 -> 69.3,
+            // 8 x 9x64x128 24.4 -> 20.5, 1 x 9x128x256 17.3 -> 13.2, but 1 x 9x64x128 (192 tiles) 7.8 -> 8.4: grids that do not
+            // fill the chip stay on the exact kernel (dispatch-bound either way)
+            if (s.mid8_form == 2 && (long)cdiv(w, 32) * cdiv(h, 4) * cdiv(D, 3) * B >= 256)
+                return mid8x_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+            if (s.mid8_form >= 1) {
                 // Tile: 3 x 8 x 32 voxels (12 waves, 54 KB of LDS, halo 2.21x) once there are enough of them to fill the chip,
                 // else 3 x 4 x 32 (6 waves, 32.6 KB, halo 2.66x).  The staging is what bounds this kernel (the CU's fetch path),
                 // so 17 % fewer halo bytes per output are worth more than the smaller tile's occupancy -- measured r03

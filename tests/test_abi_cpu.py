@@ -110,6 +110,15 @@ def test_options_validate_names_and_ranges(hip_lib):
     assert hip_lib.lws_set_option(h, b"fuse_shift", 2) == _lib.LWS_ERR_INVALID
     assert hip_lib.lws_set_option(h, b"bogus", 1) == _lib.LWS_ERR_INVALID
     assert b"unknown option" in hip_lib.lws_last_error()
+    # the opt-in numerics mode as one switch (the three options that change bits)
+    assert hip_lib.lws_get_option(h, b"split_bf16", ctypes.byref(v)) == 0 and v.value == 0
+    assert hip_lib.lws_set_option(h, b"split_bf16", 1) == 0
+    for name, want in [(b"mid16_form", 1), (b"conv64_form", 1), (b"mid8_form", 2), (b"split_bf16", 1)]:
+        assert hip_lib.lws_get_option(h, name, ctypes.byref(v)) == 0 and v.value == want
+    assert hip_lib.lws_set_option(h, b"split_bf16", 0) == 0
+    for name, want in [(b"mid16_form", 0), (b"conv64_form", 0), (b"mid8_form", 1), (b"split_bf16", 0)]:
+        assert hip_lib.lws_get_option(h, name, ctypes.byref(v)) == 0 and v.value == want
+    assert hip_lib.lws_set_option(h, b"mid8_form", 3) == _lib.LWS_ERR_INVALID
     hip_lib.lws_destroy(h)
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Conv3D stack of one stage alone (lws_conv3d_stack): per-kernel-class averages, 16x16x4 parity-row tiles (mid8_form 0) vs 4x4x1_16B (mid8_form 1) (dev aid)."""
+"""Conv3D stack of one stage alone (lws_conv3d_stack): per-kernel-class averages, 16x16x4 parity-row tiles (mid8_form 0) vs 4x4x1_16B (mid8_form 1) vs split-bf16 (mid8_form 2, not bit-exact) (dev aid)."""
 import argparse, ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,7 +21,7 @@ for o in a.opt:
     m.set_option(o.split('=')[0], int(o.split('=')[1]))
 for stage, (D, div) in ((1, (9, 4)), (2, (9, 2))):
     c = torch.rand((a.batch, D, H // div, W // div), device=dev) * 12
-    for form in (0, 1):
+    for form in (0, 1, 2):
         m.set_option("mid8_form", form)
         for _ in range(5):
             ops.conv3d_stack(m._h, stage, c)
