@@ -387,15 +387,14 @@ def main():
                      "what": f"lws_pool (C ABI): {P} C++ worker threads, each with a clone of the model and ONE HIP stream, keep "
                              f"{2 * P} batch-{B} forwards in flight so that their launch-bound chains overlap on the device; median of "
                              "3 timed repetitions; not the headline: `value` is the single-stream number"}
-    # untimed extra (single GPU, default single-stream run only): the same steps with options mid16_form = conv64_form = 1 --
-    # the stage-1 32 -> 32 Conv3D layers and refinement2[0] on split-bf16 MFMA (k_conv3d_mid16x, k_ref_conv64x: three bf16
-    # values per float32 operand, six exact cross products accumulated in float32).  An opt-in numerics mode: float32-level accuracy (tests/test_gpu_parity.py::
+    # untimed extra (single GPU, default single-stream run only): the same steps with option split_bf16 = 1 -- the Conv3D middle
+    # layers and refinement2[0] on split-bf16 MFMA (k_conv3d_mid16x, k_conv3d_mid8x, k_ref_conv64x: three bf16 values per
+    # float32 operand, six exact cross products accumulated in float32).  An opt-in numerics mode: float32-level accuracy (tests/test_gpu_parity.py::
     # test_split_bf16_*), NOT bit-exact against the oracle chain, therefore never `value` and reported with its own dtype.
     split_bf16 = None
     if (not grouped and S == 1 and not args.no_pipelined and model.get_option("mid16_form") == 0
-            and model.get_option("conv64_form") == 0 and c3_first == 32):
-        model.set_option("mid16_form", 1)
-        model.set_option("conv64_form", 1)
+            and model.get_option("conv64_form") == 0 and model.get_option("mid8_form") == 1 and c3_first == 32):
+        model.set_option("split_bf16", 1)
         try:
             for _ in range(10):
                 px = model(left, right)
@@ -416,15 +415,14 @@ def main():
             x64_us = 1e3 * totx[KC_CONV64] / max(cntx[KC_CONV64], 1)
             diff = [round(float((px[s_] - pred[s_]).abs().max()), 6) for s_ in range(4)]
             split_bf16 = {"value": round(B * nx / dtx, 2), "unit": "pairs/s", "steps": nx, "ms_per_step": round(1e3 * dtx / nx, 4),
-                          "dtype": "f32 activations / weights split into 3 x bf16 for the MFMAs of the stage-1 32->32 Conv3D layers "
-                                   "and of refinement2[0], f32 accumulate",
+                          "dtype": "f32 activations / weights split into 3 x bf16 for the MFMAs of the Conv3D middle layers and of "
+                                   "refinement2[0], f32 accumulate",
                           "k_conv3d_mid16x_avg_launch_us": round(x_us, 2), "k_ref_conv64x_avg_launch_us": round(x64_us, 2),
                           "max_abs_vs_exact_per_stage": diff,
-                          "what": "options mid16_form = conv64_form = 1: not bit-exact against the oracle chain (float32-level accuracy, gated by "
+                          "what": "option split_bf16 = 1 (mid16_form 1, mid8_form 2, conv64_form 1): not bit-exact against the oracle chain (float32-level accuracy, gated by "
                                   "the float64 noise-floor tests); an opt-in numerics mode, never the headline"}
         finally:
-            model.set_option("mid16_form", 0)
-            model.set_option("conv64_form", 0)
+            model.set_option("split_bf16", 0)
     if grouped:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -570,7 +568,7 @@ def main():
 
     pairs = world * B * args.steps
     dtype_name = "f32 (fp16-rounded features)" if args.feature_fp16 else "f32"
-    if model.get_option("mid16_form") == 1 or model.get_option("conv64_form") == 1:
+    if model.get_option("mid16_form") == 1 or model.get_option("conv64_form") == 1 or model.get_option("mid8_form") == 2:
         # experiments only (--opt): the opt-in numerics mode, float32-level accuracy but not the oracle's bits
         dtype_name += " with split-bf16 MFMA operands (3 x bf16 per f32, f32 accumulate; not bit-exact against the oracle)"
     out = {

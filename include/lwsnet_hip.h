@@ -130,8 +130,9 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
                 void *stream);
 
 /* Launch-plan options of lws_forward / lws_disparity_stages.  They change which kernels / streams carry the work, never
- * the arithmetic: every setting returns the same bits (tests/test_gpu_parity.py::test_forward_schedule_options) -- with ONE
- * exception, "mid16_form" = 1, an opt-in numerics mode (see below).
+ * the arithmetic: every setting returns the same bits (tests/test_gpu_parity.py::test_forward_schedule_options) -- except
+ * the opt-in numerics mode "split_bf16" = 1 and the three settings it stands for ("mid16_form" = 1, "mid8_form" = 2,
+ * "conv64_form" = 1; see below).
  *   "left_at"        -1 (default: 2), 0 = refinement1_left starts with the forward, 2 = beside stages 2-3
  *   "split_heads"    -1 (default: off), 0/1 = right-image feature head on its own stream
  *   "fuse_shift"     1 (default) = stage-1 volume built inside the first Conv3D launch
@@ -140,11 +141,20 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "mid8_form"      the 8 -> 8 Conv3D layers (stages 2, 3): 1 (default) = v_mfma_f32_4x4x1_16B_f32 with the A block
  *                    broadcast (k_conv3d_mid8q: 4 couts x 64 voxels per instruction, no padding), 0 = v_mfma_f32_16x16x4_f32
  *                    with rows = (x parity, cout) (k_conv3d_mid8: 25 % of every instruction is structural zero padding;
- *                    measured r03 10-25 % slower); k_conv3d_mid8q picks 3 x 8 x 32 or 3 x 4 x 32 voxel tiles by grid size
+ *                    measured r03 10-25 % slower); k_conv3d_mid8q picks 3 x 8 x 32 or 3 x 4 x 32 voxel tiles by grid size;
+ *                    2 = k_conv3d_mid8x, split-bf16 MFMA (NOT bit-exact, see "split_bf16"; grids under 256 tiles stay on
+ *                    k_conv3d_mid8q)
  *   "mid16_form"     0 (default) = the 32 -> 32 Conv3D layers on the f32-input MFMA, the oracle's fma chain bit for bit;
  *                    1 = k_conv3d_mid16x: split-bf16 MFMA (each float32 operand as three bf16 values, six exact cross
  *                    products accumulated in float32): ~2.5x the MFMA issue rate at float32-level accuracy, but NOT
  *                    bit-exact -- an opt-in numerics mode, never what bench.py's headline measures
+ *   "conv64_form"    0 (default) = refinement2[0] (64 -> 32, dilation 8) on the f32-input MFMA, bit-exact;
+ *                    1 = k_ref_conv64x, the same split-bf16 scheme (NOT bit-exact)
+ *   "split_bf16"     0 (default) / 1: one switch for the three above (sets mid16_form = conv64_form = 1, mid8_form = 2, or
+ *                    back to 0 / 0 / 1; reads 1 when all three are on).  Float32-level accuracy -- gated against the float64
+ *                    oracle by tests/test_gpu_parity.py::test_split_bf16_* -- for +17-21 % pairs/s (r03: 2,360 vs 2,010 at
+ *                    batch 1, 3,500 vs 2,935 at batch 8, 256x512), but not the oracle's bits: use it where the reference's own
+ *                    float32 noise floor is the requirement, not reproducibility against the oracle
  *   "conv3d_order"   tile order of the Conv3D kernels inside an XCD's run: 1 (default) = d fastest (the tiles that share
  *                    halo planes are co-resident: re-reads hit that XCD's L2), 0 = x fastest
  *   "side_streams"   1 (default) = refinement1_left and the feature-extractor tail run on handle-owned side streams;

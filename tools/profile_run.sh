@@ -45,5 +45,12 @@ python tools/stamps.py mid8q3 1 > "$O/stamps_mid8q_stage3_b1.txt" 2> /dev/null
 python tools/stamps.py mid8_3 8 > "$O/stamps_mid8_stage3_b8.txt" 2> /dev/null
 python -m lwsnet_amd.build --force > /dev/null 2>&1
 python tools/split_bf16_numerics.py --pairs 8 > "$O/split_bf16_numerics_64x256.txt" 2> /dev/null
+python tools/split_bf16_numerics.py --pairs 6 --size 128x384 > "$O/split_bf16_numerics_128x384.txt" 2> /dev/null
+# the opt-in numerics mode as whole steps (never the headline) and its refinement kernel
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pipelined --opt split_bf16=1 > "$O/bench_b1_split_bf16.json" 2> /dev/null
+python bench.py --batch 8 --steps 30 --warmup 5 --no-cpu-baseline --no-pipelined --opt split_bf16=1 > "$O/bench_b8_split_bf16.json" 2> /dev/null
+python bench.py --size 544x960 --maxdisp0 32 --feature-fp16 --no-cpu-baseline --no-pipelined --steps 20 --opt split_bf16=1 > "$O/bench_cfg5_split_bf16.json" 2> /dev/null
+python tools/rbench.py --opt conv64_form=1 > "$O/rbench_b1_conv64x.txt" 2> /dev/null
+python tools/rbench.py --batch 8 --iters 20 --opt conv64_form=1 > "$O/rbench_b8_conv64x.txt" 2> /dev/null
 (cd tools/micro && hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o split_bf16 split_bf16.hip && ./split_bf16 > "$O/micro_split_bf16.txt" 2>&1)
 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29535 tools/gather_probe.py 2> /dev/null | grep pairs > "$O/gather_probe.txt"

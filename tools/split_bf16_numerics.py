@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Numerics account of options mid16_form = conv64_form = 1 (k_conv3d_mid16x / k_ref_conv64x: split-bf16 MFMA in the stage-1
-32 -> 32 Conv3D layers and in refinement2[0]; --only mid16_form | conv64_form for one of them):
+"""Numerics account of option split_bf16 = 1 (k_conv3d_mid16x / k_conv3d_mid8x / k_ref_conv64x: split-bf16 MFMA in the Conv3D
+middle layers and in refinement2[0]; --only mid16_form | mid8_form | conv64_form for one of them; k_conv3d_mid8x is only selected
+for grids of >= 256 tiles, i.e. from about 128x384 up):
 per stage, max and mean |result - float64 literal oracle| of (a) the exact HIP build (the oracle's float32 chain bit for bit),
 (b) the split-bf16 build, (c) the float32 literal oracle, over several seeded pairs.  VERDICT r2 item 8: the split form is
 acceptable only if it is no further from float64 than the float32 chain is.   python tools/split_bf16_numerics.py [--pairs N]"""
@@ -12,7 +13,7 @@ import torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=6)
 ap.add_argument("--size", default="64x256")
-ap.add_argument("--only", default="", help="mid16_form or conv64_form: switch only this option (default: both)")
+ap.add_argument("--only", default="", help="mid16_form, mid8_form or conv64_form: switch only this option (default: all three)")
 a = ap.parse_args()
 H, W = [int(v) for v in a.size.split("x")]
 from lwsnet_amd.models import LWSNet
@@ -23,6 +24,15 @@ dev = torch.device("cuda:0")
 sd = make_state_dict(7)
 m = LWSNet(default_args(), device=dev).set_state_dict(sd).eval()
 torch.set_num_threads(16)
+
+
+def set_mode(on):
+    if a.only:
+        m.set_option(a.only, {"mid8_form": (1, 2)}.get(a.only, (0, 1))[int(on)])
+    else:
+        m.set_option("split_bf16", int(on))
+
+
 acc = {k: {"max": np.zeros(4), "mean": np.zeros(4)} for k in ("exact HIP", "split-bf16 HIP", "float32 literal oracle")}
 for i in range(a.pairs):
     if i == a.pairs - 1:
@@ -32,13 +42,11 @@ for i in range(a.pairs):
     l, r = l[None], r[None]
     ref64 = lws_oracle.forward(l, r, sd, (24, 5, 5), dtype=torch.float64)
     ref32 = lws_oracle.forward(l, r, sd, (24, 5, 5))
-    names = [a.only] if a.only else ["mid16_form", "conv64_form"]
-    for o in names:
-        m.set_option(o, 0)
+    set_mode(False)
     exact = [p.cpu().double() for p in m(l, r)]
-    for o in names:
-        m.set_option(o, 1)
+    set_mode(True)
     split = [p.cpu().double() for p in m(l, r)]
+    set_mode(False)
     for name, res in (("exact HIP", exact), ("split-bf16 HIP", split), ("float32 literal oracle", [p.double() for p in ref32])):
         e = [(res[s] - ref64[s]).abs() for s in range(4)]
         mx, mn = np.array([float(v.max()) for v in e]), np.array([float(v.mean()) for v in e])
