@@ -1603,7 +1603,9 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
             // 8 x 9x64x128 and 2 x 9x128x256: 34.5 and 33.3 us.)
             // split-bf16 (NOT bit-exact).  Measured r03 (tools/sbench.py, us per launch, 4x4x1 -> split): 8 x 9x128x256 81.8 -> 69.3,
             // 8 x 9x64x128 24.4 -> 20.5, 1 x 9x128x256 17.3 -> 13.2, but 1 x 9x64x128 (192 tiles) 7.8 -> 8.4: grids that do not
-            // fill the chip stay on the exact kernel (dispatch-bound either way)
+            // fill the chip stay on the exact kernel (dispatch-bound either way).  Other shapes of the same kernel, 8 x 9x128x256 /
+            // 1 x 9x128x256 / 8 x 9x184x616: 6 waves x 2 rows (142 VGPRs, 3 waves per SIMD) 96.5 / 14.7 / 381 us, 3 x 8 x 32 tiles
+            // with 12 waves 77.2 / 14.7 / 306, this one (4 waves x 3 rows, 188 VGPRs) 70.7 / 12.4 / 272.
             if (s.mid8_form == 2 && (long)cdiv(w, 32) * cdiv(h, 4) * cdiv(D, 3) * B >= 256)
                 return mid8x_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
             if (s.mid8_form >= 1) {
