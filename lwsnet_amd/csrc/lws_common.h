@@ -69,7 +69,8 @@ __device__ __forceinline__ void store_act4(float *p, float4 v, int wt)
 static inline int use_wt_stores(size_t out_bytes) { return out_bytes <= ((size_t)40 << 20) ? 1 : 0; }
 
 // Diagnostic builds only (LWS_EXTRA_FLAGS="-DLWS_STAMPS=<kernel id>"; tools/stamps.py): every workgroup of the selected
-// kernel stores s_memtime stamps of its phases in a per-translation-unit buffer.  The shipped library compiles
+// kernel stores s_memtime stamps of its phases (slots 0..5) and the s_memrealtime (100 MHz) of its first and latest stamp
+// (slots 6, 7: the in-kernel clock = d s_memtime / d s_memrealtime x 100 MHz) in a per-translation-unit buffer.  The shipped library compiles
 // LWS_STAMPK to nothing.  Kernel ids: 1 mid16, 2 mid8, 3 conv3d_last, 4 conv3d_first, 5 ref_dws, 6 ref_conv64,
 // 7 conv2d_nchw, 8 ref_first, 9 ref_last, 10 volume_warp, 11 volume_shift, 12 softargmin_upsample, 13..16 conv2d_pair (dres0, dres1, conv1+2, conv3+4), 18 conv3d_mid8q.
 #ifdef LWS_STAMPS
@@ -78,11 +79,14 @@ static inline int use_wt_stores(size_t out_bytes) { return out_bytes <= ((size_t
     static __device__ __forceinline__ void stamp_(int i)                                                           \
     {                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
-        unsigned long long t_;                                                                                     \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                \
+        unsigned long long t_, r_;                                                                                 \
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");  \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
         const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                       \
-        if (threadIdx.x == 0 && threadIdx.y == 0 && bid < 4096) g_stamps_##tu[bid * 8 + i] = t_;                   \
+        if (threadIdx.x == 0 && threadIdx.y == 0 && bid < 4096) {                                                  \
+            g_stamps_##tu[bid * 8 + i] = t_;                                                                       \
+            g_stamps_##tu[bid * 8 + (i == 0 ? 6 : 7)] = r_;   /* 100 MHz wall clock at the first / latest stamp */  \
+        }                                                                                                          \
     }                                                                                                              \
     extern "C" int lws_debug_read_stamps_##tu(unsigned long long *out, int n)                                      \
     {                                                                                                              \

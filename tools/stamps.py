@@ -2,7 +2,7 @@
 
     python tools/stamps.py <kernel> [batch]     # rebuilds the library with -DLWS_STAMPS=<id>, runs, prints medians
 kernels: mid16 mid8_2 mid8_3 mid8q2 mid8q3 last1 last3 first1 first3 dws conv64 feat pair0..pair3 ref_last warp2 warp3
-Slots: 0..3 = phase boundaries as placed in the kernel source (LWS_STAMPK)."""
+Slots: 0..3 = phase boundaries as placed in the kernel source (LWS_STAMPK); 6, 7 = s_memrealtime at the first / latest stamp."""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, '/root/repo')
 KERNELS = {  # name: (stamp id, translation unit, driver, arg)
@@ -61,7 +61,13 @@ s = np.array(buf, dtype=np.int64).reshape(-1, 8)
 s = s[(s[:, 0] > 0) & (s[:, 3] > 0)]
 last = 5 if (s[:, 5] > 0).all() else 3
 print(f"{what} B={B}: workgroups with stamps: {len(s)} (last launch of this kernel)")
-print(f"  whole launch (first start -> last end): {s[:, last].max() - s[:, 0].min()} cycles; start spread {s[:, 0].max() - s[:, 0].min()}")
+rt = (s[:, 7] - s[:, 6]).astype(np.float64)                       # 100 MHz ticks between the first and the last stamp of a workgroup
+ok = rt > 50
+clk = (s[ok, last] - s[ok, 0]) / (rt[ok] * 10.0)                  # shader cycles per ns = GHz
+print(f"  in-kernel clock (d s_memtime / d s_memrealtime, per workgroup): median {np.median(clk):.3f} GHz  p10 {np.percentile(clk, 10):.3f}  p90 {np.percentile(clk, 90):.3f}")
+# s_memrealtime is one chip-wide clock: the launch's wall time and the number of workgroups in flight follow from it
+t0, t1 = s[:, 6].min(), s[:, 7].max()
+print(f"  launch (first workgroup start -> last stamped workgroup end): {(t1 - t0) / 100.0:.1f} us; sum of workgroup lifetimes / that = {rt.sum() / max(t1 - t0, 1):.1f} workgroups in flight on average")
 for a, b in [(i, i + 1) for i in range(last)] + [(0, last)]:
     d = s[:, b] - s[:, a]
     print(f"  stamp {a}->{b}: median {np.median(d):8.0f}  p10 {np.percentile(d,10):8.0f}  p90 {np.percentile(d,90):8.0f} cycles")
