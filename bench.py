@@ -464,6 +464,9 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS
         roof = {"bound": "mfma", "kernel": "k_conv3d_mid16x<3,4> (split-bf16, NOT the oracle chain)" if split else "k_conv3d_mid16<32,3,4>",
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "peak_note": "bf16 dense peak / 6 cross products" if split else
+                             "nominal: 64 FLOP/clk/SIMD at 2.4 GHz; the in-kernel clock of this kernel reads 2.10-2.14 GHz "
+                             "(profiles/r03/stamps_inkernel_clock.txt), i.e. 138-140 TF sustainable",
                 "traffic": None, "flop_per_launch": flop_per_launch, "avg_launch_us": round(mid["avg_us"], 2),
                 "timed_launches": int(mid_n), "timed_every_nth_step": sample_every, "pairs_per_launch": pairs_per_launch}
     # the whole step against the same fp32-MFMA peak: algorithmic GF of a forward x pairs / step time.  This, not `frac`,
