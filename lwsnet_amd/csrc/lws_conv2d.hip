@@ -21,7 +21,6 @@
 
 namespace lws {
 
-typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 LWS_DEFINE_STAMPS(conv2d)
 
@@ -989,6 +988,7 @@ __global__ __launch_bounds__(64 * NW) void k_ref_conv64x(const float *__restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RefTile t = ref_tile(dil, nbx, nby, TY);
     const int n = lane & 15, g = lane >> 4;
+    LWS_STAMPK(21, 0);
 
     // stage: item = (tensor, halo pixel, 16-channel group) = 64 B of float32 -> BN + ReLU -> 3 x 32 B of bf16
     {
@@ -1043,6 +1043,7 @@ __global__ __launch_bounds__(64 * NW) void k_ref_conv64x(const float *__restrict
             wa[1][mt][v3] = wp[C64X_STEP_U4 + (mt * 3 + v3) * 64];
         }
     __syncthreads();
+    LWS_STAMPK(21, 1);
 
     floatx4 acc[RW][2];
 #pragma unroll
@@ -1052,56 +1053,44 @@ __global__ __launch_bounds__(64 * NW) void k_ref_conv64x(const float *__restrict
     const unsigned char *rptr[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) rptr[r] = ldsb + ((RW * wave + r) * RH_X + n) * VSB + g * 16;
-    auto as_frag = [](const uint4 &u) {
-        union { uint4 u4; bf16x8 v; } cv;
-        cv.u4 = u;
-        return cv.v;
-    };
-    uint4 bb[2][RW][3];
-    auto load_b = [&](uint4 (&dst)[RW][3], int off) {
+    uint4 bb[2][RW][3];                             // double-buffered by step parity; the step loop is fully unrolled
+    auto load_b_row = [&](uint4 (&dst)[RW][3], int r, int off) {
 #pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-            for (int v3 = 0; v3 < 3; ++v3) dst[r][v3] = *reinterpret_cast<const uint4 *>(rptr[r] + off + v3 * 64);
+        for (int v3 = 0; v3 < 3; ++v3) dst[r][v3] = *reinterpret_cast<const uint4 *>(rptr[r] + off + v3 * 64);
     };
-    load_b(bb[0], 0);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) load_b_row(bb[0], r, 0);
 
-#pragma unroll 1
-    for (int kh = 0; kh < 3; ++kh) {
-        const int base = kh * RH_X * VSB;
-        const int base_n = (kh < 2 ? kh + 1 : 2) * RH_X * VSB;          // (clamped: the last prefetch is unused)
-        const uint4 *wrow = wp + (size_t)(kh * 6) * C64X_STEP_U4;
+    // step = 2 tap + tensor.  One step = 6 terms x (RW x 2 accumulators); the prefetches ride in the MFMA gaps one at a time
+    // (see k_conv3d_mid16x): the next step's fragments, then the weights of step + 2 into the ring slot of step - 1
+    static_assert(2 * (3 * RW + 6) <= 6 * RW * 2, "one prefetch behind every second MFMA");
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {                                   // s = 2 kw + tensor
-            const int kw = s >> 1, cb = s & 1, nb = cb ^ 1;
-            // prefetch: the next step's activation fragments, and the weights of step + 2 into the slot of step - 1
-            const int sn = s + 1;
-            load_b(bb[nb], (sn < 6 ? base + (sn >> 1) * VSB : base_n) + (sn & 1) * NPX * VSB);
+    for (int s = 0; s < 18; ++s) {
+        const int cb = s & 1, nb = cb ^ 1;
+        const int sn = s < 17 ? s + 1 : 17;                              // (clamped: the last prefetch is unused)
+        const int off_n = (((sn >> 1) / 3) * RH_X + (sn >> 1) % 3) * VSB + (sn & 1) * NPX * VSB;
+        auto prefetch = [&](int k) {                                     // as in k_conv3d_mid16x: one load per call
+            if (k < 3 * RW)
+                bb[nb][k / 3][k % 3] = *reinterpret_cast<const uint4 *>(rptr[k / 3] + off_n + (k % 3) * 64);
+            else if (k < 3 * RW + 6)
+                wa[(s + 2) % 3][(k - 3 * RW) / 3][(k - 3 * RW) % 3] = wp[(size_t)(s + 2) * C64X_STEP_U4 + (k - 3 * RW) * 64];
+        };
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+        for (int T = 0; T < 6; ++T)
 #pragma unroll
-                for (int v3 = 0; v3 < 3; ++v3) wa[(s + 2) % 3][mt][v3] = wrow[(size_t)(s + 2) * C64X_STEP_U4 + (mt * 3 + v3) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-            (void)kw;
-#pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                const bf16x8 bh = as_frag(bb[cb][r][0]), bm = as_frag(bb[cb][r][1]), bl = as_frag(bb[cb][r][2]);
+            for (int r = 0; r < RW; ++r)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    const bf16x8 ah = as_frag(wa[s % 3][mt][0]), am = as_frag(wa[s % 3][mt][1]), al = as_frag(wa[s % 3][mt][2]);
-                    floatx4 a = acc[r][mt];                 // smallest terms first
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, a, 0, 0, 0);
-                    acc[r][mt] = a;
+                    acc[r][mt] = mfma_split_bf16_term(acc[r][mt], wa[s % 3][mt], bb[cb][r], T);
+                    const int m = (T * RW + r) * 2 + mt;                 // one prefetch behind every second MFMA
+                    if (m % 2 == 0 && m / 2 < 3 * RW + 6) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        prefetch(m / 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
     }
+    LWS_STAMPK(21, 2);
     float *outb = out + (int64_t)t.b * H * W * 32;
     const int gx = t.X0 + n * dil;
 #pragma unroll
@@ -1114,6 +1103,7 @@ __global__ __launch_bounds__(64 * NW) void k_ref_conv64x(const float *__restrict
                 store_act4(o + mt * 16 + 4 * g, make_float4(acc[r][mt][0], acc[r][mt][1], acc[r][mt][2], acc[r][mt][3]), wt);
         }
     }
+    LWS_STAMPK(21, 3);
 }
 
 // =============================================================================================

@@ -24,7 +24,6 @@
 
 namespace lws {
 
-typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 LWS_DEFINE_STAMPS(conv3d)
 
@@ -357,6 +356,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid16x(const float *__restrict__
     const int b = blockIdx.y;
     const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * C3;
+    LWS_STAMPK(19, 0);
 
     // ---- stage: item = (voxel, 16-channel group) = 64 B of float32 -> 3 x 32 B of bf16 (hi / mid / lo)
     float4 c[SITER][4];
@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid16x(const float *__restrict__
 #pragma unroll
     for (int i = 0; i < P1; ++i) stage_write(i);
     __syncthreads();
+    LWS_STAMPK(19, 1);
 
     floatx4 acc[RW][MT];
 #pragma unroll
@@ -429,73 +430,63 @@ __global__ __launch_bounds__(256) void k_conv3d_mid16x(const float *__restrict__
         const int row = wave * RW + r;
         rptr[r] = ldsb + ((row / TY * HY + row % TY) * HX + n) * VSB + g * 16;
     }
-    auto as_frag = [](const uint4 &u) {
-        union { uint4 u4; bf16x8 v; } cv;
-        cv.u4 = u;
-        return cv.v;
-    };
-    // activation fragments of one tap: RW rows x (hi, mid, lo); double-buffered by tap parity inside a (kd,kh) iteration --
-    // 3 taps per iteration, so the buffers of consecutive iterations are reconciled with one copy per iteration
+    // activation fragments of one tap: RW rows x (hi, mid, lo), double-buffered by tap parity (the tap loop is fully unrolled,
+    // so every buffer index and LDS offset is a compile-time constant)
     uint4 bb[2][RW][3];
-    auto load_b = [&](uint4 (&dst)[RW][3], int off) {
+    auto load_b_row = [&](uint4 (&dst)[RW][3], int r, int off) {
 #pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) dst[r][t] = *reinterpret_cast<const uint4 *>(rptr[r] + off + t * 64);
+        for (int t = 0; t < 3; ++t) dst[r][t] = *reinterpret_cast<const uint4 *>(rptr[r] + off + t * 64);
     };
-    load_b(bb[0], 0);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) load_b_row(bb[0], r, 0);
 
-#pragma unroll 1
-    for (int kdh = 0; kdh < 9; ++kdh) {
-        const int kd = kdh / 3, kh = kdh - kd * 3;
-        const int base = (kd * HY + kh) * HX * VSB;
-        const int kn = kdh < 8 ? kdh + 1 : 8;                          // (clamped: the prefetch of the last iteration is unused)
-        const int base_n = ((kn / 3) * HY + (kn % 3)) * HX * VSB;
-        const uint4 *wtap = wp + (size_t)(kdh * 3) * Cfg::TAP_U4;
-        if (P1 < SITER && kdh == 3) {
-            // phase 2 of the staging (halo planes TD, TD + 1, first read by kd = 1); the fragments prefetched at the end of
-            // iteration 2 may predate these writes: read again
+    // One tap = 6 terms x (RW x MT = 6 accumulators) = 36 MFMAs of 16 cycles, of which each holds the vector issue port for 8.
+    // The 15 prefetches of a tap ride in those gaps ONE at a time, fenced behind every second MFMA: the next tap's fragments
+    // (9 ds_read_b128), then the weights of tap + 2 into the ring slot of tap - 1 (6 global loads).  Measured r03
+    // (tools/stamps.py mid16x, cycles per MFMA over the MFMA phase): all prefetches in one block ahead of the tap's MFMAs 22.6,
+    // one slice of 3 behind each term group 20.0, one at a time 19.0 -- and 15.9 / 14.8 / 15.1 us per launch at B = 1: the last
+    // step came back as a lower clock (1.99 -> 1.95 GHz in-kernel), not as time (MI355X_MICROARCH.md, DVFS give-back).
+    static_assert(2 * (3 * RW + 3 * MT) <= 6 * RW * MT, "one prefetch behind every second MFMA");
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        const int kw = tap % 3, kdh = tap / 3;
+        const int cb = tap & 1, nb = cb ^ 1;
+        const int tn = tap < 26 ? tap + 1 : 26;                          // (clamped: the last prefetch is unused)
+        const int off_n = (((tn / 9) * HY + (tn / 3) % 3) * HX + tn % 3) * VSB;
+        if (P1 < SITER && tap == 9) {
+            // phase 2 of the staging (halo planes TD, TD + 1, first read by kd = 1); the fragments prefetched during tap 8
+            // may predate these writes: read again
 #pragma unroll
             for (int i = P1; i < SITER; ++i) stage_write(i);
             __syncthreads();
-            load_b(bb[0], base);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) load_b_row(bb[cb], r, ((kdh / 3) * HY + kdh % 3) * HX * VSB);
         }
+        // prefetch op k of this tap: k < 3 RW = one ds_read_b128 (row k / 3, variant k % 3) of the next tap's fragments, then
+        // one global load each of the weights of tap + 2 (cout tile, variant) into the ring slot of tap - 1
+        auto prefetch = [&](int k) {
+            if (k < 3 * RW)
+                bb[nb][k / 3][k % 3] = *reinterpret_cast<const uint4 *>(rptr[k / 3] + off_n + (k % 3) * 64);
+            else if (k < 3 * RW + 3 * MT)
+                wa[(kw + 2) % 3][(k - 3 * RW) / 3][(k - 3 * RW) % 3] = wp[(size_t)(tap + 2) * Cfg::TAP_U4 + (k - 3 * RW) * 64];
+        };
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int cb = kw & 1, nb = cb ^ 1;                         // compile-time buffers: kw = 0, 1, 2 -> 0, 1, 0
-            // prefetch: the next tap's activation fragments, and the weights of tap + 2 into the slot of tap - 1
-            load_b(bb[nb], kw < 2 ? base + (kw + 1) * VSB : base_n);
+        for (int T = 0; T < 6; ++T)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) wa[(kw + 2) % 3][mt][t] = wtap[(size_t)(kw + 2) * Cfg::TAP_U4 + (mt * 3 + t) * 64];
-            // (fence: left to itself hipcc sinks every prefetch to its first use and waits on it there)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                const bf16x8 bh = as_frag(bb[cb][r][0]), bm = as_frag(bb[cb][r][1]), bl = as_frag(bb[cb][r][2]);
+            for (int r = 0; r < RW; ++r)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const bf16x8 ah = as_frag(wa[kw][mt][0]), am = as_frag(wa[kw][mt][1]), al = as_frag(wa[kw][mt][2]);
-                    floatx4 a = acc[r][mt];                 // smallest terms first
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, a, 0, 0, 0);
-                    acc[r][mt] = a;
+                    acc[r][mt] = mfma_split_bf16_term(acc[r][mt], wa[kw][mt], bb[cb][r], T);
+                    const int m = (T * RW + r) * MT + mt;               // one prefetch behind every second MFMA
+                    if (m % 2 == 0 && m / 2 < 3 * RW + 3 * MT) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        prefetch(m / 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // kw = 2 prefetched the next iteration's first tap into buffer 1; iterations start from buffer 0
-#pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) bb[0][r][t] = bb[1][r][t];
     }
 
+    LWS_STAMPK(19, 2);
     // ---- epilogue (as k_conv3d_mid16): row i = 4 (lane >> 4) + reg = output channel in the tile, col = lane & 15 = voxel
     float *outb = out + (int64_t)b * D * h * w * C3;
     const int gx = x0 + n;
@@ -517,6 +508,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid16x(const float *__restrict__
             }
         }
     }
+    LWS_STAMPK(19, 3);
 }
 
 // =============================================================================================
@@ -715,6 +707,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8x(const float *__restrict__ 
     const int b = blockIdx.y;
     const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * 8;
+    LWS_STAMPK(20, 0);
 
     float4 c[SITER][2];
     bool okv[SITER];
@@ -760,6 +753,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8x(const float *__restrict__ 
 #pragma unroll
     for (int i = 0; i < P1; ++i) stage_write(i);
     __syncthreads();
+    LWS_STAMPK(20, 1);
 
     floatx4 acc[RW];
     int rbase[RW];                                  // halo voxel (rd, ry, 2 n + g) of this lane's row
@@ -769,62 +763,53 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8x(const float *__restrict__ 
         const int row = wave * RW + r;
         rbase[r] = (row / TY * HY + row % TY) * HX + 2 * n + g;
     }
-    auto as_frag = [](const uint4 &u) {
-        union { uint4 u4; bf16x8 v; } cv;
-        cv.u4 = u;
-        return cv.v;
-    };
-    uint4 bb[2][RW][3];
-    auto load_b = [&](uint4 (&dst)[RW][3], int off) {
+    uint4 bb[2][RW][3];                             // double-buffered by step parity; the step loop is fully unrolled
+    auto load_b_row = [&](uint4 (&dst)[RW][3], int r, int off) {
+        const unsigned char *p = ldsb + mid8x_slot(rbase[r] + off);
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            const unsigned char *p = ldsb + mid8x_slot(rbase[r] + off);
-#pragma unroll
-            for (int t = 0; t < 3; ++t) dst[r][t] = *reinterpret_cast<const uint4 *>(p + t * PLANE);
-        }
+        for (int t = 0; t < 3; ++t) dst[r][t] = *reinterpret_cast<const uint4 *>(p + t * PLANE);
     };
-    load_b(bb[0], 0);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) load_b_row(bb[0], r, 0);
 
-#pragma unroll 1
-    for (int kd = 0; kd < 3; ++kd) {
-        const int base = kd * HY * HX;
-        const int base_n = (kd < 2 ? kd + 1 : 2) * HY * HX;           // (clamped: the prefetch of the last iteration is unused)
-        const uint4 *wrow = wp + (size_t)(kd * 3) * Cfg::STEP_U4;
-        if (P1 < SITER && kd == 1) {
-            // phase 2 of the staging (halo planes TD, TD + 1); the fragments prefetched at the end of kd = 0 may predate it
+    // One step = 6 terms x RW accumulators; the prefetches ride in the MFMA gaps one at a time (see k_conv3d_mid16x): the next
+    // step's fragments, then the weights of step + 2
+    static_assert(3 * RW + 3 <= 6 * RW, "one prefetch behind an MFMA");
+#pragma unroll
+    for (int step = 0; step < 9; ++step) {
+        const int kd = step / 3, kh = step % 3;
+        const int cb = step & 1, nb = cb ^ 1;
+        const int sn = step < 8 ? step + 1 : 8;                          // (clamped: the last prefetch is unused)
+        const int off_n = ((sn / 3) * HY + sn % 3) * HX;
+        if (P1 < SITER && step == 3) {
+            // phase 2 of the staging (halo planes TD, TD + 1); the fragments prefetched during step 2 may predate it
 #pragma unroll
             for (int i = P1; i < SITER; ++i) stage_write(i);
             __syncthreads();
-            load_b(bb[0], base);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) load_b_row(bb[cb], r, (kd * HY + kh) * HX);
         }
+        auto prefetch = [&](int k) {                                     // as in k_conv3d_mid16x: one load per call
+            if (k < 3 * RW)
+                bb[nb][k / 3][k % 3] = *reinterpret_cast<const uint4 *>(ldsb + mid8x_slot(rbase[k / 3] + off_n) + (k % 3) * PLANE);
+            else if (k < 3 * RW + 3)
+                wa[(kh + 2) % 3][k - 3 * RW] = wp[(size_t)(step + 2) * Cfg::STEP_U4 + (k - 3 * RW) * 64];
+        };
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int cb = kh & 1, nb = cb ^ 1;
-            load_b(bb[nb], kh < 2 ? base + (kh + 1) * HX : base_n);
-#pragma unroll
-            for (int t = 0; t < 3; ++t) wa[(kh + 2) % 3][t] = wrow[(size_t)(kh + 2) * Cfg::STEP_U4 + t * 64];
-            __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 ah = as_frag(wa[kh][0]), am = as_frag(wa[kh][1]), al = as_frag(wa[kh][2]);
+        for (int T = 0; T < 6; ++T)
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
-                const bf16x8 bh = as_frag(bb[cb][r][0]), bm = as_frag(bb[cb][r][1]), bl = as_frag(bb[cb][r][2]);
-                floatx4 a = acc[r];                     // smallest terms first
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, a, 0, 0, 0);
-                acc[r] = a;
+                acc[r] = mfma_split_bf16_term(acc[r], wa[kh], bb[cb][r], T);
+                const int m = T * RW + r;                                // 18 MFMAs, 12 prefetches: one behind each of the first 12
+                if (m < 3 * RW + 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    prefetch(m);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) bb[0][r][t] = bb[1][r][t];
     }
 
+    LWS_STAMPK(20, 2);
     // ---- epilogue (as k_conv3d_mid8): row i = 4*(lane>>4) + reg -> xpar = (lane>>4)>>1, cout = 4*((lane>>4)&1) + reg
     float *outb = out + (int64_t)b * D * h * w * 8;
     const int gx = x0 + 2 * n + xpar;
@@ -841,6 +826,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8x(const float *__restrict__ 
             store_act4(outb + (((int64_t)gd * h + gy) * w + gx) * 8 + cb8, v, 0);
         }
     }
+    LWS_STAMPK(20, 3);
 }
 
 // =============================================================================================

@@ -16,6 +16,7 @@ __device__ __forceinline__ int xcd_tile(int b, int nb)
 
 // ---- split-bf16 ("bf16x3") helpers of the opt-in numerics mode (k_conv3d_mid16x, k_ref_conv64x) -------------------------
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // float32 -> bf16 bits, round to nearest even (finite values; the activations are BN + ReLU outputs)
 __host__ __device__ __forceinline__ uint32_t f2bf_bits(float x)
@@ -58,6 +59,24 @@ __device__ __forceinline__ void split_bf16x3_pair(float x0, float x1, uint32_t &
     r0 = r0 - __uint_as_float(m << 16);
     r1 = r1 - __uint_as_float(m & 0xffff0000u);
     l = pack_bf16x2(r0, r1);
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const uint4 &u)
+{
+    union { uint4 u4; bf16x8 v; } cv;
+    cv.u4 = u;
+    return cv.v;
+}
+// One term of  acc += W * X  for a 16 x 16 tile and a K = 32 block, W and X given as their (hi, mid, lo) bf16 fragments: the six
+// cross terms of total order <= 2, smallest first -- T = 0 lo*hi, 1 hi*lo, 2 mid*mid, 3 mid*hi, 4 hi*mid, 5 hi*hi -- each
+// product exact in float32 and summed by v_mfma_f32_16x16x32_bf16.  Callers run T in the OUTER loop over their accumulators
+// (T a compile-time constant after unrolling): consecutive instructions then belong to different accumulators and issue every
+// 16 cycles; the six terms of one accumulator back to back are paced by the dependency (18-25 cycles each, tools/stamps.py).
+__device__ __forceinline__ floatx4 mfma_split_bf16_term(floatx4 a, const uint4 (&w)[3], const uint4 (&x)[3], int T)
+{
+    const int wi = T == 0 ? 2 : (T == 2 || T == 3) ? 1 : 0;
+    const int xi = T == 1 ? 2 : (T == 2 || T == 4) ? 1 : 0;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w[wi]), as_bf16x8(x[xi]), a, 0, 0, 0);
 }
 
 // exp(x) for x <= 0 from IEEE mul / fma / rint only (Cephes expf polynomial), so the result is a

@@ -1,7 +1,7 @@
 """Diagnostic: per-workgroup phase stamps (s_memtime, shader cycles) of one kernel.
 
     python tools/stamps.py <kernel> [batch]     # rebuilds the library with -DLWS_STAMPS=<id>, runs, prints medians
-kernels: mid16 mid8_2 mid8_3 mid8q2 mid8q3 last1 last3 first1 first3 dws conv64 feat pair0..pair3 ref_last warp2 warp3
+kernels: mid16 mid16x mid8_2 mid8_3 mid8q2 mid8q3 mid8x2 mid8x3 conv64x last1 last3 first1 first3 dws conv64 feat pair0..pair3 ref_last warp2 warp3
 Slots: 0..3 = phase boundaries as placed in the kernel source (LWS_STAMPK); 6, 7 = s_memrealtime at the first / latest stamp."""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, '/root/repo')
@@ -15,6 +15,8 @@ KERNELS = {  # name: (stamp id, translation unit, driver, arg)
     "pair2": (15, "conv2d", "feat", None), "pair3": (16, "conv2d", "feat", None), "ref_last": (9, "conv2d", "refine", None),
     "warp2": (10, "volume", "stages", None), "warp3": (10, "volume", "stages", None),
     "mid8q3": (18, "conv3d", "stack", 2), "mid8q2": (18, "conv3d", "stack", 1),
+    "mid16x": (19, "conv3d", "stack", 0), "mid8x3": (20, "conv3d", "stack", 2), "mid8x2": (20, "conv3d", "stack", 1),
+    "conv64x": (21, "conv2d", "refine", None),
 }
 what = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -30,6 +32,8 @@ m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
 lib = ctypes.CDLL(_lib.LIB_PATH)
 if kid == 18:
     m.set_option("mid8_form", 1)
+if kid in (19, 20, 21):
+    m.set_option({19: "mid16_form", 20: "mid8_form", 21: "conv64_form"}[kid], 2 if kid == 20 else 1)
 if kid == 2:
     m.set_option("mid8_form", 0)
 if driver == "stack":
