@@ -152,8 +152,8 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *                    1 = k_ref_conv64x, the same split-bf16 scheme (NOT bit-exact)
  *   "split_bf16"     0 (default) / 1: one switch for the three above (sets mid16_form = conv64_form = 1, mid8_form = 2, or
  *                    back to 0 / 0 / 1; reads 1 when all three are on).  Float32-level accuracy -- gated against the float64
- *                    oracle by tests/test_gpu_parity.py::test_split_bf16_* -- for +17-21 % pairs/s (r03: 2,360 vs 2,010 at
- *                    batch 1, 3,500 vs 2,935 at batch 8, 256x512), but not the oracle's bits: use it where the reference's own
+ *                    oracle by tests/test_gpu_parity.py::test_split_bf16_* -- for +20-26 % pairs/s (r03: 2,418 vs 2,000 at
+ *                    batch 1, 3,707 vs 2,950 at batch 8, 256x512), but not the oracle's bits: use it where the reference's own
  *                    float32 noise floor is the requirement, not reproducibility against the oracle
  *   "conv3d_order"   tile order of the Conv3D kernels inside an XCD's run: 1 (default) = d fastest (the tiles that share
  *                    halo planes are co-resident: re-reads hit that XCD's L2), 0 = x fastest
