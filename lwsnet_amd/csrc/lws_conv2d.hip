@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv2d_pair(const float *__restrict
     const int iy0 = my0 * SA - DA, ix0 = mx0 * SA - DA;           // pad == dilation for every layer of the extractor
     const int plane = H * W;
     const float *inb = b < n1 ? in + (int64_t)b * CIN * plane : in2 + (int64_t)(b - n1) * CIN * plane;
-    constexpr int STAMP_ID = 13 + (CIN == 3 ? 0 : CM == 4 ? 1 : CIN == 8 ? 2 : 3);   // diagnostic builds only
+    [[maybe_unused]] constexpr int STAMP_ID = 13 + (CIN == 3 ? 0 : CM == 4 ? 1 : CIN == 8 ? 2 : 3);   // diagnostic builds only
     LWS_STAMPK(STAMP_ID, 0);
     // phase 1: input region, item = (channel, region pixel); unconditional clamped loads, masked afterwards
     {
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(512) void k_conv2d_pair_mfma(const float *__restric
     const int iy0 = my0 * 2 - 1, ix0 = mx0 * 2 - 1;
     const int plane = H * W;
     const float *inb = b < n1 ? in + (int64_t)b * CIN * plane : in2 + (int64_t)(b - n1) * CIN * plane;
-    constexpr int STAMP_ID = CIN == 8 ? 15 : 16;
+    [[maybe_unused]] constexpr int STAMP_ID = CIN == 8 ? 15 : 16;
     LWS_STAMPK(STAMP_ID, 0);
     {
         float v[SITER];
