@@ -34,6 +34,9 @@ def build_parser():
     p.add_argument("--vis", action="store_true", default=False)
     p.add_argument("--synthetic_weights", action="store_true",
                    help="use the seeded synthetic weights instead of --model (the reference ships no checkpoint)")
+    p.add_argument("--split_bf16", action="store_true",
+                   help="opt-in numerics mode of this build (not in the reference): MFMA convolutions on split-bf16 operands, "
+                        "float32-level accuracy, +20-25 %% speed, not bit-identical to the default (include/lwsnet_hip.h)")
     return p
 
 
@@ -98,6 +101,9 @@ def main(argv=None):
         model.set_state_dict(load_state_dict(args.model))
         log.info("Successful load model")
     model.eval()
+    if getattr(args, "split_bf16", False):
+        model.set_option("split_bf16", 1)
+        log.info("split-bf16 numerics mode")
     if not args.left_img:                                               # :50-63
         if os.path.isdir(args.img_path):
             lefts = sorted(glob.glob(os.path.join(args.img_path, "image_2/*.png")))
