@@ -112,6 +112,29 @@ def test_conv3d_stack_bitexact(dev, model, stage, shape):
         assert_bits(got, want, f"conv3d_stack stage {stage} {shape} mid8_form={form}")
 
 
+@pytest.mark.parametrize("stage", [0, 1, 2])
+def test_conv3d_stack_ragged_sweep(dev, model, stage):
+    """Seeded random volume shapes -- every extent down to 1, extents that are not multiples of any tile edge (3 x 4 x 16,
+    3 x 4 x 32, 3 x 8 x 32 voxels; the 32-wide parity rows of the 8 -> 8 kernels), tiles that are all halo -- through
+    lws_conv3d_stack against the C oracle, bit for bit, in every exact kernel form (the tile choice follows the grid size)."""
+    from lwsnet_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.default_rng(100 + stage)
+    shapes = [(1, 1, 1, 1), (1, 2, 1, 3), (2, 1, 5, 1), (1, 3, 4, 33), (1, 4, 9, 31)]
+    for _ in range(9):
+        shapes.append((int(rng.integers(1, 4)), int(rng.integers(1, 27)), int(rng.integers(1, 42)), int(rng.integers(1, 90))))
+    for shape in shapes:
+        c = (rng.random(shape) * 12.0).astype(np.float32)
+        want = C.conv3d_stack(c, model.state_dict(), stage)
+        for form in ((0, 1) if stage > 0 else (0,)):
+            model.set_option("mid8_form", form)
+            try:
+                got = ops.conv3d_stack(model._h, stage, cu(c, dev))
+            finally:
+                model.set_option("mid8_form", 1)
+            assert_bits(got, want, f"conv3d_stack stage {stage} {shape} mid8_form={form}")
+
+
 @pytest.mark.parametrize("stage", [0, 1])
 def test_conv3d_stack_golden(dev, model, stage):
     from lwsnet_amd import ops
@@ -204,6 +227,22 @@ def test_refine_bitexact(dev, model, B, H, W, chunk_mb):
     finally:
         model.set_option("ref_chunk_mb", 72)
     assert_bits(got, C.refine(left, pred3, model.state_dict()), "refine")
+
+
+def test_refine_ragged_sweep(dev, model):
+    """lws_refine accepts any H, W > 0 (include/lwsnet_hip.h): seeded random sizes from a single pixel up, none a multiple of
+    the 8 x 16 phase-grid tile or of the largest dilation (16), against the C oracle bit for bit."""
+    from lwsnet_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.default_rng(77)
+    sizes = [(1, 1, 1), (1, 1, 40), (2, 3, 2), (1, 17, 15), (1, 16, 129)]
+    for _ in range(5):
+        sizes.append((int(rng.integers(1, 3)), int(rng.integers(1, 70)), int(rng.integers(1, 150))))
+    for B, H, W in sizes:
+        left = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+        pred3 = (rng.random((B, 1, H, W)) * 150.0).astype(np.float32)
+        got = ops.refine(model._h, cu(left, dev), cu(pred3, dev))
+        assert_bits(got, C.refine(left, pred3, model.state_dict()), f"refine {B}x{H}x{W}")
 
 
 def test_forward_bitexact_vs_c_oracle(dev, model):
