@@ -648,6 +648,26 @@ def test_forward_other_constructor_args(dev, hip_lib):
         assert_bits(pred[s], want[s], f"non-default args, stage {s + 1}")
 
 
+@pytest.mark.parametrize("mdl,l3,c3,gr", [((24, 5, 5), 4, 8, (1, 1, 1)), ((16, 2, 6), 2, 8, (4, 2, 1)), ((8, 1, 1), 1, 16, (1, 1, 1)),
+                                          ((24, 5, 5), 1, 8, (4, 1, 1)), ((12, 4, 2), 3, 8, (2, 2, 2)), ((24, 7, 9), 4, 8, (4, 1, 1)),
+                                          ((30, 5, 5), 4, 8, (4, 4, 4))])
+def test_forward_constructor_sweep(dev, hip_lib, mdl, l3, c3, gr):
+    """The constructor's degrees of freedom (models/models.py:8-22) beyond the CLI defaults: every channel count the library
+    accepts (8 / 16 / 32) at every stage, 1-4 middle layers, hypothesis counts from D = 1 (maxdisplist entry 1: a single
+    residual hypothesis, the soft-argmin of one value) through 3, 7, 11, 13, 17 to 30 -- last layers fused with the soft-argmin
+    or not, every Conv3D kernel family on every stage.  Two pairs at 64x256, all four stage maps bit for bit the C oracle's."""
+    from lwsnet_amd.models import LWSNet
+    from oracle import c_oracle as C
+    args = default_args(maxdisplist=mdl, layers_3d=l3, channels_3d=c3, growth_rate=gr)
+    sd = make_state_dict(13, args, calibrated=False)
+    m = LWSNet(args, device=dev).set_state_dict(sd).eval()
+    left, right = make_batch(2, 64, 256, 4)
+    pred = m(left, right)
+    want = C.forward(left, right, sd, maxdisplist=mdl)
+    for s in range(4):
+        assert_bits(pred[s], want[s], f"maxdisplist={mdl} layers_3d={l3} channels_3d={c3} growth_rate={gr} stage {s + 1}")
+
+
 def test_forward_matches_literal_oracle(dev, model):
     """LWSNet.forward end to end (all kernels native) vs the literal oracle's golden stage maps."""
     g = golden("e2e_64x256.npz")
