@@ -155,6 +155,27 @@ def test_c_oracle_within_reference_noise_floor(name, factor):
         assert mine <= factor * floor + 1e-4, f"{name} stage {i + 1}: {mine:.3e} vs reference float32 floor {floor:.3e}"
 
 
+@pytest.mark.parametrize("mdl,l3,c3,gr", [((16, 2, 6), 2, 8, (4, 2, 1)), ((8, 1, 1), 1, 16, (1, 1, 1)), ((24, 5, 5), 1, 8, (4, 1, 1)),
+                                          ((12, 4, 2), 3, 8, (2, 2, 2))])
+def test_c_oracle_constructor_sweep_tracks_the_literal_oracle(mdl, l3, c3, gr):
+    """The constructor configurations tests/test_gpu_parity.py::test_forward_constructor_sweep pins the HIP path to (other
+    channel counts per stage, 1-3 middle layers, D = 1 / 3 / 7 / 11 hypotheses): the C restatement against the literal
+    oracle's float64 run, per stage no further away than 3 x the literal oracle's own float32 run (+1e-4 px).  Uncalibrated
+    BatchNorm statistics (activations and 'disparities' of 1e3): single samples of a heavy-tailed maximum, hence the factor."""
+    from lwsnet_amd.synth import make_batch
+    from lwsnet_amd.weights import default_args
+    args = default_args(maxdisplist=mdl, layers_3d=l3, channels_3d=c3, growth_rate=gr)
+    sd = make_state_dict(13, args, calibrated=False)
+    left, right = make_batch(1, 32, 256, 4)
+    got = C.forward(left, right, sd, maxdisplist=mdl)
+    p32 = O.forward(left, right, sd, mdl, torch.float32)
+    p64 = O.forward(left, right, sd, mdl, torch.float64)
+    for i in range(4):
+        floor = float(np.abs(p32[i].numpy().astype(np.float64) - p64[i].numpy()).max())
+        mine = float(np.abs(got[i].astype(np.float64) - p64[i].numpy()).max())
+        assert mine <= 3.0 * floor + 1e-4, f"{mdl} {l3} {c3} {gr} stage {i + 1}: {mine:.3e} vs literal float32 floor {floor:.3e}"
+
+
 def test_c_oracle_odd_size_matches_reference_source():
     """H, W = 8k-1 (63x255) is legal for the reference: the stem convolution (submodules.py:118-125, k3 s2 dil2 pad2)
     gives ceil(H/2).  Stage maps are 8x32 / 16x64 / 32x128 and every resize has a non-integer ratio."""
