@@ -418,6 +418,41 @@ def test_pool_returns_the_bits_of_forward(dev, model, side_streams):
     assert len(outs) == 6 and all(torch.equal(a, b) for o, w in zip(outs, want) for a, b in zip(o, w))
 
 
+def test_pool_reports_a_workers_error_at_wait(dev, model, hip_lib):
+    """The C ABI underneath LWSNet.pool (the Python face validates sizes before it submits): a job whose geometry lws_forward
+    refuses is accepted by lws_pool_submit, fails on the worker thread, and lws_pool_wait returns THAT job's status and message
+    to the waiting thread; jobs before and after it are unaffected, lws_pool_wait_all reports the first failure."""
+    import ctypes
+    from lwsnet_amd import _lib
+    left, right = make_batch(1, 64, 256, 33)
+    lt, rt = cu(left, dev), cu(right, dev)
+    want = model(lt, rt)
+    bad_l = torch.zeros((1, 3, 30, 256), device=dev)                     # ceil(30 / 2) = 15 is not a multiple of 4
+    outs = [[torch.empty((1, 1, 64, 256), device=dev) for _ in range(4)] for _ in range(3)]
+    with model.pool(workers=2) as pool:
+        pool.reserve(1, 64, 256)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        def submit(l, r, H, W, o):
+            t = ctypes.c_int64(-1)
+            ptrs = (ctypes.c_void_p * 4)(*[x.data_ptr() for x in o])
+            rc = hip_lib.lws_pool_submit(pool._p, ctypes.c_void_p(l.data_ptr()), ctypes.c_void_p(r.data_ptr()), 1, H, W, ptrs,
+                                         stream, ctypes.byref(t))
+            assert rc == 0, hip_lib.lws_last_error()
+            return t.value
+        t0 = submit(lt, rt, 64, 256, outs[0])
+        t1 = submit(bad_l, bad_l, 30, 256, outs[1])
+        t2 = submit(lt, rt, 64, 256, outs[2])
+        assert hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(t1)) == _lib.LWS_ERR_INVALID
+        assert b"30" in hip_lib.lws_last_error()
+        assert hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(t0)) == 0 and hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(t2)) == 0
+        assert hip_lib.lws_pool_wait_all(pool._p) == _lib.LWS_ERR_INVALID
+        assert hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(t2 + 1)) == _lib.LWS_ERR_INVALID          # never issued
+        torch.cuda.synchronize()
+        for o in (outs[0], outs[2]):
+            assert all(torch.equal(a, b) for a, b in zip(o, want))
+
+
 def test_clone_shares_parameters(dev, model, hip_lib):
     """lws_clone: a second handle on the same parameter slab; it refuses set_tensor / finalize and returns the same bits."""
     import ctypes
