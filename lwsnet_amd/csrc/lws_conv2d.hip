@@ -685,14 +685,17 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
         const int gy0 = t.Y0 - DWS_FD - 1, gx0 = t.X0 - DWS_FD - 1;
         float iv[4];
         bool iok[4];
+        int iys[4], ixs[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int r = tid + 256 * k;
             const int ry = r / DWS_FC, rx = r - ry * DWS_FC;
             const int gy = gy0 + ry, gx = gx0 + rx;
             iok[k] = r < DWS_FR * DWS_FC && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            iv[k] = deferred_at(dm, iok[k] ? gy : 0, iok[k] ? gx : 0, H, W);
+            iys[k] = iok[k] ? gy : 0;
+            ixs[k] = iok[k] ? gx : 0;
         }
+        deferred_at_n<4>(dm, iys, ixs, H, W, iv);       // all loads of the four points in flight together
         float4 wq[9];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) wq[tap] = *reinterpret_cast<const float4 *>(wf + tap * 32 + c4 * 4);

@@ -131,8 +131,10 @@ __global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict_
         src_index(x, rw, W, x0, x1, wx0, wx1);
         const DeferredMap dm{plow != nullptr ? plow + (int64_t)b * ph * pw : nullptr, prev + (int64_t)b * H * W, ph, pw,
                              (float)H, 1.0f / (float)(ph > 0 ? ph : 1)};
-        const float q00 = deferred_at(dm, y0, x0, H, W), q01 = deferred_at(dm, y0, x1, H, W);
-        const float q10 = deferred_at(dm, y1, x0, H, W), q11 = deferred_at(dm, y1, x1, H, W);
+        const int tys[4] = {y0, y0, y1, y1}, txs[4] = {x0, x1, x0, x1};
+        float q[4];
+        deferred_at_n<4>(dm, tys, txs, H, W, q);
+        const float q00 = q[0], q01 = q[1], q10 = q[2], q11 = q[3];
         if (pmat != nullptr && k == 0) {
             float *pm = pmat + (int64_t)b * H * W;
             pm[(int64_t)y0 * W + x0] = q00;
