@@ -86,6 +86,11 @@ static inline int use_wt_stores(size_t out_bytes) { return out_bytes <= ((size_t
         if (threadIdx.x == 0 && threadIdx.y == 0 && bid < 4096) {                                                  \
             g_stamps_##tu[bid * 8 + i] = t_;                                                                       \
             g_stamps_##tu[bid * 8 + (i == 0 ? 6 : 7)] = r_;   /* 100 MHz wall clock at the first / latest stamp */  \
+            if (i == 0) {   /* slot 5: where the workgroup runs -- HW_ID (cu 11:8, sh 12, se 15:13) | XCC_ID << 32 */      \
+                unsigned hw_, xcc_;                                                                                \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_), "=s"(xcc_)); \
+                g_stamps_##tu[bid * 8 + 5] = ((unsigned long long)(xcc_ & 15u) << 32) | hw_;                        \
+            }                                                                                                      \
         }                                                                                                          \
     }                                                                                                              \
     extern "C" int lws_debug_read_stamps_##tu(unsigned long long *out, int n)                                      \

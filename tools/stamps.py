@@ -63,7 +63,10 @@ buf = (ctypes.c_ulonglong * n)()
 assert getattr(lib, "lws_debug_read_stamps_" + TU)(buf, n) == 0
 s = np.array(buf, dtype=np.int64).reshape(-1, 8)
 s = s[(s[:, 0] > 0) & (s[:, 3] > 0)]
-last = 5 if (s[:, 5] > 0).all() else 3
+last = 3            # (slot 5 holds the hardware id of the CU since round 3; kernels stamp phases 0..3)
+hw = s[:, 5]
+cu = ((hw >> 32) & 15) * 64 + ((hw >> 13) & 7) * 16 + ((hw >> 12) & 1) * 8 + ((hw >> 8) & 15)      # xcc, se, sh, cu
+
 print(f"{what} B={B}: workgroups with stamps: {len(s)} (last launch of this kernel)")
 rt = (s[:, 7] - s[:, 6]).astype(np.float64)                       # 100 MHz ticks between the first and the last stamp of a workgroup
 ok = rt > 50
@@ -72,6 +75,23 @@ print(f"  in-kernel clock (d s_memtime / d s_memrealtime, per workgroup): median
 # s_memrealtime is one chip-wide clock: the launch's wall time and the number of workgroups in flight follow from it
 t0, t1 = s[:, 6].min(), s[:, 7].max()
 print(f"  launch (first workgroup start -> last stamped workgroup end): {(t1 - t0) / 100.0:.1f} us; sum of workgroup lifetimes / that = {rt.sum() / max(t1 - t0, 1):.1f} workgroups in flight on average")
+if (hw > 0).any():
+    ids, counts = np.unique(cu, return_counts=True)
+    # peak number of this kernel's workgroups alive at once on one CU
+    peak = 0
+    for c in ids:
+        ev = sorted([(a, 1) for a in s[cu == c, 6]] + [(b, -1) for b in s[cu == c, 7]])
+        n = 0
+        for _, d in ev:
+            n += d
+            peak = max(peak, n)
+    if os.environ.get("LWS_STAMPS_VERBOSE"):
+        for c in ids[:6]:
+            iv = sorted(((a - t0) / 100.0, (b - t0) / 100.0) for a, b in zip(s[cu == c, 6], s[cu == c, 7]))
+            print(f"    CU {c}: " + "  ".join(f"[{a:.1f}, {b:.1f}]" for a, b in iv))
+    print(f"  CUs used: {len(ids)}; workgroups per CU: min {counts.min()} median {int(np.median(counts))} max {counts.max()}; most workgroups alive at once on one CU: {peak}")
+st = (s[:, 6] - t0) / 100.0
+print("  workgroup start times after the first (us): " + "  ".join(f"p{q}={np.percentile(st, q):.1f}" for q in (10, 25, 50, 75, 90, 100)))
 for a, b in [(i, i + 1) for i in range(last)] + [(0, last)]:
     d = s[:, b] - s[:, a]
     print(f"  stamp {a}->{b}: median {np.median(d):8.0f}  p10 {np.percentile(d,10):8.0f}  p90 {np.percentile(d,90):8.0f} cycles")
