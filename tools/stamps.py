@@ -2,7 +2,11 @@
 
     python tools/stamps.py <kernel> [batch]     # rebuilds the library with -DLWS_STAMPS=<id>, runs, prints medians
 kernels: mid16 mid16x mid8_2 mid8_3 mid8q2 mid8q3 mid8x2 mid8x3 conv64x last1 last3 first1 first3 dws conv64 feat pair0..pair3 ref_last warp2 warp3
-Slots: 0..3 = phase boundaries as placed in the kernel source (LWS_STAMPK); 6, 7 = s_memrealtime at the first / latest stamp."""
+Slots: 0..3 = phase boundaries as placed in the kernel source (LWS_STAMPK); 5 = hardware id of the CU (HW_ID | XCC_ID << 32);
+6, 7 = s_memrealtime at the first / latest stamp.
+CAUTION: a stamped build is a different kernel.  The inline asm can change its register allocation (k_ref_last: 129 registers in
+the shipped build, 300 with stamps -- one workgroup per CU instead of three): compare `.amdhsa_next_free_vgpr` of the two builds
+(hipcc --save-temps) before reading residency or phase times off a stamped run."""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, '/root/repo')
 KERNELS = {  # name: (stamp id, translation unit, driver, arg)
