@@ -104,14 +104,14 @@ int launch_upsample_add(const float *low, const float *prev, float *out, int B, 
 // Conv3D layer cannot span D): a workgroup computes the low-resolution disparities of a 4 x 8 pixel tile plus a
 // one-pixel ring into LDS, then writes the (4*s) x (8*s) full-resolution pixels they determine (s = H/h).
 // ---------------------------------------------------------------------------------------------
-constexpr int SU_TY = 4, SU_TX = 8, SU_HY = SU_TY + 2, SU_HX = SU_TX + 2;
-
-template <int DT>
+// Tile: 4 x 8 low-resolution pixels, or 2 x 4 when that leaves most CUs without a workgroup (one pair at 256x512: 64 tiles).
+template <int DT, int SU_TY, int SU_TX>
 __global__ __launch_bounds__(256) void k_softargmin_upsample(const float *__restrict__ cost,
                                                              const float *__restrict__ prev, float *__restrict__ out,
                                                              float *__restrict__ low_out, int D, int h, int w, int H,
                                                              int W, float start, float mul_a, float mul_b)
 {
+    constexpr int SU_HY = SU_TY + 2, SU_HX = SU_TX + 2;
     __shared__ float sLow[SU_HY * SU_HX];
     const int tid = threadIdx.x, b = blockIdx.z;
     const int ly0 = blockIdx.y * SU_TY, lx0 = blockIdx.x * SU_TX;
@@ -179,11 +179,16 @@ __global__ __launch_bounds__(256) void k_softargmin_upsample(const float *__rest
 int launch_softargmin_upsample(const float *cost, const float *prev, float *out, float *low_out, int B, int D, int h,
                                int w, int H, int W, float start, hipStream_t st)
 {
-    dim3 grid(cdiv(w, SU_TX), cdiv(h, SU_TY), B), block(256);
+    const bool small = (long)cdiv(w, 8) * cdiv(h, 4) * B < 256;
+    dim3 grid(cdiv(w, small ? 4 : 8), cdiv(h, small ? 2 : 4), B), block(256);
     const float mul_a = (float)H, mul_b = 1.0f / (float)h;
-#define LWS_SU(DT)                                                                                                  \
-    hipLaunchKernelGGL(k_softargmin_upsample<DT>, grid, block, 0, st, cost, prev, out, low_out, D, h, w, H, W, start, \
-                       mul_a, mul_b)
+#define LWS_SU(DT)                                                                                                              \
+    if (small)                                                                                                                  \
+        hipLaunchKernelGGL((k_softargmin_upsample<DT, 2, 4>), grid, block, 0, st, cost, prev, out, low_out, D, h, w, H, W, start, \
+                           mul_a, mul_b);                                                                                       \
+    else                                                                                                                        \
+        hipLaunchKernelGGL((k_softargmin_upsample<DT, 4, 8>), grid, block, 0, st, cost, prev, out, low_out, D, h, w, H, W, start, \
+                           mul_a, mul_b)
     switch (D) {
         case 9: LWS_SU(9); break;
         case 24: LWS_SU(24); break;
