@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void k_ref_first(const float *__restrict__ in,
     float acc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
-#pragma unroll 1
+#pragma unroll 3
     for (int tap = 0; tap < 9; ++tap) {
         const int kh = tap / 3, kw = tap - kh * 3;
         const int iy = y + kh - 1, ix = x + kw - 1;
