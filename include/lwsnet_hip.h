@@ -162,6 +162,9 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "ref_chunk_mb"   72 (default): the refinement runs in chunks of pairs whose [b,H,W,32] maps are at most this many MB
  *                    each, so that a chunk's maps stay in the 256 MiB Infinity Cache between layers (batch 8 at 256x512:
  *                    two chunks of 4; 368x1232: one pair per chunk); 0 = one chunk
+ *   "ref_pipe"       -1 (default: on from four chunks up), 0 / 1: consecutive refinement chunks alternate between the caller's
+ *                    stream and the handle's side stream, one chunk's memory-bound blocks beside the other's 64 -> 32 convolution
+ *                    (r03: 810 -> 833 pairs/s at 8 x 368x1232; two chunks only, 8 x 256x512: 2,958 -> 2,930, hence the default)
  *   "device"         the HIP device the handle belongs to; settable only before lws_finalize / lws_reserve allocate
  * Unknown names and out-of-range values return LWS_ERR_INVALID. */
 int lws_set_option(lws_handle h, const char *name, int value);

@@ -582,27 +582,48 @@ struct DeferState {
 static bool refine_can_defer(const lws_ctx *h);
 
 static int refine_rest_chunk(lws_ctx *h, float *pred3, int B, int H, int W, const WsLayout &L, float *pred4, hipStream_t st,
-                             const DeferState *ds, const float *pred2, int b0);
+                             const DeferState *ds, const float *pred2, int b0, int scratch_b0 = 0, hipEvent_t after_disp = nullptr);
 
 static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLayout &L, float *pred4,
                        hipStream_t st, const DeferState *ds = nullptr, const float *pred2 = nullptr)
 {
     const int CH = (ds != nullptr && ds->def[2]) ? B : refine_chunk(h, B, H, W);      // (deferred maps: batches <= 2, one chunk)
-    for (int b0 = 0; b0 < B; b0 += CH) {
+    // Option "ref_pipe": chunks alternate between the caller's stream and the side stream (idle by now), each starting once the
+    // previous chunk has finished its disparity branch, so that one chunk's memory-bound blocks run beside the other's MFMA-bound
+    // 64 -> 32 convolution; odd chunks use the second half of the (batch-sized) scratch maps.  Measured r03: 8 x 368x1232 (eight
+    // chunks of one pair) 810 -> 833 pairs/s; 8 x 256x512 (two chunks of four) 2,958 -> 2,930: two chunks only add their
+    // collisions, hence the automatic setting wants at least four.
+    const int nchunks = (B + CH - 1) / CH;
+    const int want = h->opt.ref_pipe >= 0 ? h->opt.ref_pipe : (nchunks >= 4 ? 1 : 0);
+    const bool pipe = want != 0 && h->side != nullptr && h->opt.side_streams != 0 && nchunks >= 2 && 2 * CH <= B;
+    if (pipe) {
+        LWS_HIP(hipEventRecord(h->ev_fork, st));
+        LWS_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    }
+    int k = 0;
+    for (int b0 = 0; b0 < B; b0 += CH, ++k) {
         const size_t po = (size_t)b0 * H * W;
-        const int rc = refine_rest_chunk(h, pred3 + po, std::min(CH, B - b0), H, W, L, pred4 + po, st, ds,
-                                         pred2 != nullptr ? pred2 + po : nullptr, b0);
+        hipStream_t cs = (pipe && (k & 1)) ? h->side : st;
+        if (pipe && k > 0) LWS_HIP(hipStreamWaitEvent(cs, h->ev_feat[(k - 1) & 1], 0));
+        const int rc = refine_rest_chunk(h, pred3 + po, std::min(CH, B - b0), H, W, L, pred4 + po, cs, ds,
+                                         pred2 != nullptr ? pred2 + po : nullptr, b0, pipe ? (k & 1) * CH : 0,
+                                         pipe ? h->ev_feat[k & 1] : nullptr);
         if (rc) return rc;
+    }
+    if (pipe) {
+        LWS_HIP(hipEventRecord(h->ev_join, h->side));
+        LWS_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     }
     return LWS_OK;
 }
 
 static int refine_rest_chunk(lws_ctx *h, float *pred3, int B, int H, int W, const WsLayout &L, float *pred4, hipStream_t st,
-                             const DeferState *ds, const float *pred2, int b0)
+                             const DeferState *ds, const float *pred2, int b0, int scratch_b0, hipEvent_t after_disp)
 {
     const Net2d &n = h->net2d;
     // r_a: this chunk's slice (refinement1_left's result); r_b, r_c: the same memory for every chunk
-    float *ra = h->ws + L.r_a + (size_t)b0 * H * W * 32, *rb = h->ws + L.r_b, *rc_ = h->ws + L.r_c;
+    float *ra = h->ws + L.r_a + (size_t)b0 * H * W * 32, *rb = h->ws + L.r_b + (size_t)scratch_b0 * H * W * 32,
+          *rc_ = h->ws + L.r_c + (size_t)scratch_b0 * H * W * 32;
     int rc;
     if (h->opt.fuse_first && ref_first_dws_can_fuse(n.r1[1][0], 1)) {
         // refinement1_disp: the 1 -> 32 convolution is recomputed inside the first block's staging (one launch less)
@@ -621,6 +642,7 @@ static int refine_rest_chunk(lws_ctx *h, float *pred3, int B, int H, int W, cons
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][1], rc_, rb, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][2], rb, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[1][3], rc_, rb, B, H, W, st));
+    if (after_disp != nullptr) LWS_HIP(hipEventRecord(after_disp, st));
     LWS_RF(LWS_KC_REF_CONV64, launch_ref_conv64(n.r2_first, ra, rb, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[0], rc_, ra, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[1], ra, rc_, B, H, W, st));
@@ -838,6 +860,7 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"mid16_form", &h->opt.mid16_form},
                                                      {"conv64_form", &h->opt.conv64_form},
                                                      {"ref_chunk_mb", &h->opt.ref_chunk_mb},
+                                                     {"ref_pipe", &h->opt.ref_pipe},
                                                      {"device", &h->device},
                                                      {"mid8_form", &h->opt.mid8_form}};
     for (auto &e : tab)
@@ -861,8 +884,8 @@ int lws_set_option(lws_handle h, const char *name, int value)
     LWS_CHECK_ARG(slot != nullptr, "lws_set_option: unknown option '%s'", name);
     if (strcmp(name, "left_at") == 0)
         LWS_CHECK_ARG(value == -1 || value == 0 || value == 2, "lws_set_option: left_at must be -1 (auto), 0 or 2 (got %d)", value);
-    else if (strcmp(name, "split_heads") == 0)
-        LWS_CHECK_ARG(value >= -1 && value <= 1, "lws_set_option: split_heads must be -1 (auto), 0 or 1 (got %d)", value);
+    else if (strcmp(name, "split_heads") == 0 || strcmp(name, "ref_pipe") == 0)
+        LWS_CHECK_ARG(value >= -1 && value <= 1, "lws_set_option: %s must be -1 (auto), 0 or 1 (got %d)", name, value);
     else if (strcmp(name, "ref_chunk_mb") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 4096, "lws_set_option: ref_chunk_mb must be in 0..4096 (got %d)", value);
     else if (strcmp(name, "device") == 0) {

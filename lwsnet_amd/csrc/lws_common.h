@@ -179,6 +179,7 @@ struct lws_ctx {
         int mid16_form = 0;        // 1: stage-1 middle Conv3D layers on split-bf16 MFMA (k_conv3d_mid16x): float32-level accuracy, NOT bit-exact
         int conv64_form = 0;       // 1: refinement2[0] (64 -> 32, dilation 8) on split-bf16 MFMA (k_ref_conv64x): NOT bit-exact
         int conv3d_order = 1;      // tile order of the Conv3D stacks: 0 = x fastest, 1 = d fastest (halo planes shared inside an XCD's L2)
+        int ref_pipe = -1;         // refinement chunks alternating over two streams: -1 = from four chunks up, 0 = never, 1 = from two chunks up
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
     } opt;
     unsigned prof_mask = 0;                  // kernel classes being timed in the current call

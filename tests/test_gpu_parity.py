@@ -212,6 +212,33 @@ def test_feature_extraction_golden(dev, model):
         np.testing.assert_allclose(got[i].cpu().numpy(), g[f"featL{i}"], rtol=0, atol=3e-5)
 
 
+def test_refine_chunks_over_two_streams(dev, model):
+    """Option ref_pipe: consecutive chunks on alternating streams (the caller's and the handle's side stream), staggered by one
+    disparity branch, odd chunks in the second half of the scratch maps.  Five pairs in chunks of one and of two (a ragged last
+    chunk), forced on: the C oracle's bits, and the bits of the same call with the option off; inside lws_forward as well."""
+    from lwsnet_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.default_rng(21)
+    B, H, W = 5, 64, 256
+    left = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    pred3 = (rng.random((B, 1, H, W)) * 150.0).astype(np.float32)
+    want = C.refine(left, pred3, model.state_dict())
+    l2, r2 = make_batch(B, H, W, 300)
+    model.set_option("ref_pipe", 0)
+    fwd_off = [p.clone() for p in model(l2, r2)]
+    try:
+        for chunk_mb in (3, 5):                         # one map = 2.1 MB: chunks of 1 and of 2 pairs
+            model.set_option("ref_chunk_mb", chunk_mb)
+            model.set_option("ref_pipe", 1)
+            for _ in range(3):                          # back to back: the event reuse across calls
+                assert_bits(ops.refine(model._h, cu(left, dev), cu(pred3, dev)), want, f"refine ref_pipe chunk_mb={chunk_mb}")
+            fwd_on = model(l2, r2)
+            assert all(torch.equal(a, b) for a, b in zip(fwd_on, fwd_off)), f"forward ref_pipe chunk_mb={chunk_mb}"
+    finally:
+        model.set_option("ref_chunk_mb", 72)
+        model.set_option("ref_pipe", -1)
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 64, 256), (2, 40, 72), (1, 136, 152), (1, 63, 255)])
 @pytest.mark.parametrize("chunk_mb", [72, 1])
 def test_refine_bitexact(dev, model, B, H, W, chunk_mb):
