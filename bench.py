@@ -229,7 +229,7 @@ def main():
     # 14-18 % with 16.  Two staging buffers alternate, so the asynchronous gather of one overlaps the forwards that fill the
     # other; every step's map is gathered inside the timed region (the tail is flushed before the clock stops).
     G = max(1, -(-args.gather_pairs // B)) if grouped else 1
-    sg = ldist.StagedGather(B, H, W, G, dev) if grouped else None
+    sg = ldist.StagedGather(B, H, W, G, dev, multi_stream=S > 1) if grouped else None
     counter = [0]
 
     def step():

@@ -165,6 +165,10 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "ref_pipe"       -1 (default: on from four chunks up), 0 / 1: consecutive refinement chunks alternate between the caller's
  *                    stream and the handle's side stream, one chunk's memory-bound blocks beside the other's 64 -> 32 convolution
  *                    (r03: 810 -> 833 pairs/s at 8 x 368x1232; two chunks only, 8 x 256x512: 2,958 -> 2,930, hence the default)
+ *   "warp_form"      residual volumes of stages 2 and 3: 1 (default) = k_volume_l1_warp stages the right-feature window of a
+ *                    64-pixel row segment (all channels, zero-filled outside the image) in LDS and computes the 2m - 1
+ *                    hypotheses from it; 0 = every tap gathered from global memory (the form a tile falls back to when its
+ *                    flow range needs more than 160 window columns)
  *   "device"         the HIP device the handle belongs to; settable only before lws_finalize / lws_reserve allocate
  * Unknown names and out-of-range values return LWS_ERR_INVALID. */
 int lws_set_option(lws_handle h, const char *name, int value);

@@ -42,14 +42,32 @@ def load_state_dict(path):
         obj = _NumpyOnlyUnpickler(io.BytesIO(f.read())).load()
     if not isinstance(obj, (dict, collections.OrderedDict)):
         raise ValueError(f"{path}: expected a dict of arrays, got {type(obj).__name__}")
+    return _state_from_saved(obj, path)
+
+
+def _state_from_saved(obj, path="<checkpoint>"):
+    """The dict `paddle.save` pickled -> {structured name: float32 ndarray}.
+
+    2.0.0rc0 (`_build_saved_state_dict`): `{structured name: ndarray}` plus `"StructuredToParameterName@@"`, a dict from
+    structured names to Paddle's internal parameter names (`conv2d_0.w_0`, `batch_norm_3.w_1`, ...); 2.0 final may add
+    `"UnpackBigParamInfor@@"` (arrays above 1 GB split into slices: none here, so its presence with entries is refused).
+    >= 2.1 (`reduce_varbase`): every tensor as a `(parameter name, ndarray)` tuple, no name table."""
     out = {}
     for k, v in obj.items():
-        if k == "StructuredToParameterName@@":
+        if not isinstance(k, str):
+            raise ValueError(f"{path}: key {k!r} is not a string")
+        if k.endswith("@@"):
+            if k == "UnpackBigParamInfor@@" and v:
+                raise ValueError(f"{path}: the checkpoint holds arrays split by paddle.save ({sorted(v)}): not supported")
+            if not isinstance(v, (dict, collections.OrderedDict)):
+                raise ValueError(f"{path}: bookkeeping entry '{k}' is {type(v).__name__}, not a dict")
             continue
-        if isinstance(v, tuple) and len(v) == 2 and isinstance(v[1], np.ndarray):
+        if isinstance(v, (tuple, list)) and len(v) == 2 and isinstance(v[0], str) and isinstance(v[1], np.ndarray):
             v = v[1]
         if not isinstance(v, np.ndarray):
             raise ValueError(f"{path}: entry '{k}' is {type(v).__name__}, not an ndarray")
+        if v.dtype.kind != "f":
+            raise ValueError(f"{path}: entry '{k}' has dtype {v.dtype}, expected a floating-point array")
         out[k] = np.ascontiguousarray(v, dtype=np.float32)
     return out
 

@@ -700,11 +700,12 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
             ProfScope p(h, LWS_KC_VOLUME_WARP, st);
             rc = launch_volume_l1_warp(featsL[s], featsR[s], pred_out[s - 2], raw, nullptr, B, feat_c[s], hh, ww, H, W,
                                        h->cfg.maxdisplist[s], st, h->cfg.feature_fp16 != 0, ds->low[s - 1], ds->lh[s - 1],
-                                       ds->lw[s - 1], pred_out[s - 1]);
+                                       ds->lw[s - 1], pred_out[s - 1], h->opt.warp_form);
         } else {
             ProfScope p(h, LWS_KC_VOLUME_WARP, st);
             rc = launch_volume_l1_warp(featsL[s], featsR[s], pred_out[s - 1], raw, nullptr, B, feat_c[s], hh, ww, H, W,
-                                       h->cfg.maxdisplist[s], st, h->cfg.feature_fp16 != 0);                  // :119-127
+                                       h->cfg.maxdisplist[s], st, h->cfg.feature_fp16 != 0, nullptr, 0, 0, nullptr,
+                                       h->opt.warp_form);                                                     // :119-127
         }
         if (rc) return rc;
         const float start = s == 0 ? 0.0f : (float)(-h->cfg.maxdisplist[s] + 1);
@@ -861,6 +862,7 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"conv64_form", &h->opt.conv64_form},
                                                      {"ref_chunk_mb", &h->opt.ref_chunk_mb},
                                                      {"ref_pipe", &h->opt.ref_pipe},
+                                                     {"warp_form", &h->opt.warp_form},
                                                      {"device", &h->device},
                                                      {"mid8_form", &h->opt.mid8_form}};
     for (auto &e : tab)

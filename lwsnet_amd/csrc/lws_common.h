@@ -180,6 +180,7 @@ struct lws_ctx {
         int conv64_form = 0;       // 1: refinement2[0] (64 -> 32, dilation 8) on split-bf16 MFMA (k_ref_conv64x): NOT bit-exact
         int conv3d_order = 1;      // tile order of the Conv3D stacks: 0 = x fastest, 1 = d fastest (halo planes shared inside an XCD's L2)
         int ref_pipe = -1;         // refinement chunks alternating over two streams: -1 = from four chunks up, 0 = never, 1 = from two chunks up
+        int warp_form = 1;         // residual volumes: 1 = right-feature window of a 64-pixel row segment staged in LDS, 0 = every tap gathered from global memory
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
     } opt;
     unsigned prof_mask = 0;                  // kernel classes being timed in the current call
@@ -218,7 +219,8 @@ int launch_volume_l1_shift(const float *L, const float *R, float *cost, int B, i
                            hipStream_t st, bool q16 = false);
 int launch_volume_l1_warp(const float *L, const float *R, const float *prev, float *cost, float *wflow_out,
                           int B, int C, int h, int w, int H, int W, int m, hipStream_t st, bool q16 = false,
-                          const float *plow = nullptr, int ph = 0, int pw = 0, float *pmat = nullptr);   // deferred prev map
+                          const float *plow = nullptr, int ph = 0, int pw = 0, float *pmat = nullptr,     // deferred prev map
+                          int form = 1);   // 1 = right-feature window staged in LDS, 0 = every tap gathered from global memory
 int launch_softargmin(const float *cost, float *low, int B, int D, int h, int w, float start, hipStream_t st);
 int launch_upsample_add(const float *low, const float *prev, float *out, int B, int h, int w, int H, int W,
                         hipStream_t st);

@@ -654,10 +654,10 @@ constexpr int DWS_FD = 2, DWS_FR = (RH_Y - 1) * DWS_FD + 3, DWS_FC = (RH_X - 1) 
 static_assert(DWS_FR * DWS_FC <= 1024 && DWS_FR * DWS_FC <= 8 * DWS_SB * 4, "first-conv window must fit 4 loads/thread and sB");
 
 template <bool FIRST>
-__global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, const float *__restrict__ wf,
+__global__ __launch_bounds__(256, 4) void k_ref_dws(const float *__restrict__ in, const float *__restrict__ wf,
                                                  const float *__restrict__ bn_s,
-                                                 const float *__restrict__ bn_t, const float *__restrict__ dw,   // [tap][32]
-                                                 const float4 *__restrict__ pwpk,                              // [q][mt][lane]
+                                                 const float *__restrict__ bn_t, const float *dw,   // [tap][32]
+                                                 const float4 *pwpk,                              // [q][mt][lane]
                                                  float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt,
                                                  const float *__restrict__ plow, int ph, int pw, float *__restrict__ pmat)
 {
@@ -709,28 +709,27 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
             if (gy < H && gx < W)
                 pmat[(int64_t)t.b * H * W + (int64_t)gy * W + gx] = sImg[((ty + 1) * DWS_FD + 1) * DWS_FC + (tx + 1) * DWS_FD + 1];
         }
-#pragma unroll
+        // the 32 channels of every halo pixel, BN + ReLU applied, straight into sA (two iterations per trip: the fully unrolled
+        // loop kept all 54 window reads and 6 results live -- 188 VGPRs, two workgroups per CU instead of four)
+#pragma unroll 2
         for (int i = 0; i < SITER; ++i) {
             const int hp = (tid >> 3) + 32 * i;
             const int hy = hp / RH_X, hx = hp - hy * RH_X;
             const int gy = t.Y0 + (hy - 1) * DWS_FD, gx = t.X0 + (hx - 1) * DWS_FD;
-            okv[i] = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const bool ok = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const float *sp = sImg + (hp < NPX ? (hy * DWS_FD) * DWS_FC + hx * DWS_FD : 0);
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const float v = sp[kh * DWS_FC + kw];
-                    const float4 w = wq[kh * 3 + kw];
-                    a.x = fmaf(v, w.x, a.x);
-                    a.y = fmaf(v, w.y, a.y);
-                    a.z = fmaf(v, w.z, a.z);
-                    a.w = fmaf(v, w.w, a.w);
+                    fma4s(a, sp[kh * DWS_FC + kw], wq[kh * 3 + kw]);      // four output channels: two v_pk_fma_f32
                 }
-            c[i] = a;
+            float4 v = bn_relu4(a, s4, t4);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp < NPX) sA[c4 * DWS_SA + hp] = v;
         }
-        __syncthreads();          // sImg (= sB) is dead from here; sB is first written after the next barrier anyway
+        __syncthreads();          // sImg (= sB) is dead from here; sA is complete
     } else {
         const float *inb = in + (int64_t)t.b * H * W * 32;
 #pragma unroll
@@ -752,15 +751,16 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
     float4 wd[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) wd[tap] = *reinterpret_cast<const float4 *>(dw + tap * 32 + c4 * 4);
+    if (!FIRST) {
 #pragma unroll
-    for (int i = 0; i < SITER; ++i) {
-        const int hp = (tid >> 3) + 32 * i;
-        float4 v = make_float4(bn_relu2(c[i].x, s4.x, t4.x), bn_relu2(c[i].y, s4.y, t4.y), bn_relu2(c[i].z, s4.z, t4.z),
-                               bn_relu2(c[i].w, s4.w, t4.w));
-        if (!okv[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (hp < NPX) sA[c4 * DWS_SA + hp] = v;
+        for (int i = 0; i < SITER; ++i) {
+            const int hp = (tid >> 3) + 32 * i;
+            float4 v = bn_relu4(c[i], s4, t4);
+            if (!okv[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp < NPX) sA[c4 * DWS_SA + hp] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     LWS_STAMPK(5, 1);
 
     // 2. depthwise: tile pixel p = (tid >> 3) + 32 i  ->  row (tid >> 7) + 2 i, column (tid >> 3) & 15
@@ -775,12 +775,7 @@ __global__ __launch_bounds__(256) void k_ref_dws(const float *__restrict__ in, c
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const float4 a = src[(2 * i + kh) * RH_X + kw];
-                    const float4 w = wd[kh * 3 + kw];
-                    acc.x = fmaf(a.x, w.x, acc.x);
-                    acc.y = fmaf(a.y, w.y, acc.y);
-                    acc.z = fmaf(a.z, w.z, acc.z);
-                    acc.w = fmaf(a.w, w.w, acc.w);
+                    fma4(acc, src[(2 * i + kh) * RH_X + kw], wd[kh * 3 + kw]);   // four channels: two v_pk_fma_f32
                 }
             // channel 16q + 4a_ + e -> plane 4q + e, element a_ (the 4x4 transpose the MFMA B operand wants)
             dst[(0 * DWS_SB + 32 * i) * 4] = acc.x;

@@ -79,6 +79,35 @@ __device__ __forceinline__ floatx4 mfma_split_bf16_term(floatx4 a, const uint4 (
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w[wi]), as_bf16x8(x[xi]), a, 0, 0, 0);
 }
 
+// ---- packed float32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two independent IEEE operations per lane and
+// instruction, the way the chip reaches its vector-FP32 peak).  Bit-identical to the scalar operation on each half, so a
+// kernel may pack any two INDEPENDENT chains (two output channels, two pixels) without changing a bit.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2_t pk_fma(f2_t a, f2_t b, f2_t c) { return __builtin_elementwise_fma(a, b, c); }
+// acc.{x,y,z,w} = fmaf(a.{x,..}, w.{x,..}, acc.{x,..}) as two packed instructions
+__device__ __forceinline__ void fma4(float4 &acc, const float4 &a, const float4 &w)
+{
+    const f2_t lo = pk_fma((f2_t){a.x, a.y}, (f2_t){w.x, w.y}, (f2_t){acc.x, acc.y});
+    const f2_t hi = pk_fma((f2_t){a.z, a.w}, (f2_t){w.z, w.w}, (f2_t){acc.z, acc.w});
+    acc = make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+// acc.{x,..} = fmaf(v, w.{x,..}, acc.{x,..}) (one scalar against four weights)
+__device__ __forceinline__ void fma4s(float4 &acc, float v, const float4 &w)
+{
+    const f2_t vv = {v, v};
+    const f2_t lo = pk_fma(vv, (f2_t){w.x, w.y}, (f2_t){acc.x, acc.y});
+    const f2_t hi = pk_fma(vv, (f2_t){w.z, w.w}, (f2_t){acc.z, acc.w});
+    acc = make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+// max(fmaf(x, s, t), 0) on four channels: BatchNorm(eval) + ReLU
+__device__ __forceinline__ float4 bn_relu4(const float4 &x, const float4 &s, const float4 &t)
+{
+    const f2_t z = {0.0f, 0.0f};
+    const f2_t lo = __builtin_elementwise_max(pk_fma((f2_t){x.x, x.y}, (f2_t){s.x, s.y}, (f2_t){t.x, t.y}), z);
+    const f2_t hi = __builtin_elementwise_max(pk_fma((f2_t){x.z, x.w}, (f2_t){s.z, s.w}, (f2_t){t.z, t.w}), z);
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
 // exp(x) for x <= 0 from IEEE mul / fma / rint only (Cephes expf polynomial), so the result is a
 // pure function of the float32 input on any IEEE machine; returns 0 below -80 (e^-80 ~ 1.8e-35).
 __device__ __forceinline__ float lws_expf(float x)

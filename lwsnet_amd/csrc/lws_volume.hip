@@ -92,143 +92,288 @@ int launch_volume_l1_shift(const float *L, const float *R, float *cost, int B, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// Stage-2/3 residual volume.  One thread = one (pixel, hypothesis k); grid.y = k so that a
-// wave reads 64 consecutive pixels of one row.  The 9x expansion of L, R and disp the
-// reference materialises (models.py:85-99) is pure index arithmetic here.  The previous
-// disparity is resized on the fly (4 taps); the right features are gathered straight from
-// L2/L1: neighbouring lanes sample neighbouring columns because the flow is smooth.
-// The south taps are only touched when iy is not an exact integer (a wave-uniform branch,
-// exact because x + 0*v == x for finite v).
+// Stage-2/3 residual volume (round 4: the design north_star describes).  One workgroup = one row
+// segment of 64 pixels of one image, three waves.
+//   phase A  every wave loads the left features of its pixel into registers (C coalesced loads);
+//            wave 0 also evaluates the flow of the 64 pixels -- the previous disparity resized on
+//            the fly, models.py:119-121 -- ONCE per pixel, and from it the tile's column window
+//            [min x0, max x0 + 1] (x0 is monotone in the hypothesis k, so the bounds come from
+//            k = 0 and k = 2m-2) with a wave reduction;
+//   phase B  the right-feature window of all C channels, rows fy0 (and fy0 + 1 when iy is not an
+//            integer: a row property), is staged in LDS channel-innermost with ZEROS outside the
+//            image -- grid_sample's zero padding -- so the taps need no masks (s + 0*w == s up to
+//            the sign of zero, which |l - s| discards);
+//   phase C  wave j computes hypotheses k = j, j+3, ...: two (four) 16-byte LDS reads per four
+//            channels, the lerp and |l - s| on packed float32 pairs (v_pk_mul_f32 / v_pk_add_f32;
+//            -ffp-contract=off: no fused multiply-add), the channel sum sequential and ascending.
+// The 9x expansion of L, R and disp the reference materialises (models.py:85-99) is index
+// arithmetic.  The float32 coordinate round trip (normalise :45-48, grid_sample un-normalise) is
+// replayed op for op.  A tile whose flow range needs more than WARP_NCMAX columns falls back
+// (workgroup-uniform) to gathering the taps from global memory with the same arithmetic.
 // ---------------------------------------------------------------------------------------------
+constexpr int WARP_TX = 64;        // pixels per workgroup
+constexpr int WARP_NW = 3;         // waves per workgroup (hypotheses k = wave, wave + 3, ...)
+constexpr int WARP_NCMAX = 160;    // LDS window columns (64 + flow range of the tile + 2m + 1)
+
+struct WarpRow {      // row quantities of grid_sample (depend on y only)
+    float wy0, wy1;   // fy1 - iy, iy - fy0
+    int y0;           // clamped floor(iy)
+    bool south;       // iy is not an integer: rows y0 and y0 + 1 both contribute
+};
+
+__device__ __forceinline__ WarpRow warp_row(int y, int h)
+{
+    const float rh = 1.0f / (float)(h - 1 > 1 ? h - 1 : 1);
+    const float fh1 = (float)(h - 1);
+    const float gy = (2.0f * (float)y) * rh - 1.0f;           // models.py:48
+    const float iy = ((gy + 1.0f) / 2.0f) * fh1;              // grid_sample un-normalise (align_corners=True)
+    const float fy0 = floorf(iy), fy1 = fy0 + 1.0f;
+    const float cy = fy0 < -2.0f ? -2.0f : (fy0 > (float)h ? (float)h : fy0);
+    WarpRow r;
+    r.wy0 = fy1 - iy;
+    r.wy1 = iy - fy0;
+    r.y0 = (int)cy;
+    r.south = (iy - fy0) != 0.0f;                             // else w_sw == w_se == 0 exactly
+    return r;
+}
+
+// column quantities of one (pixel, hypothesis): x0 = clamped floor(ix), wx0 = fx1 - ix, wx1 = ix - fx0
+__device__ __forceinline__ void warp_col(float wf, int k, int m, int x, int w, float rw, float fw1, int &x0, float &wx0,
+                                         float &wx1)
+{
+    const float sk = (float)(k - (m - 1));
+    const float delta = wf - sk;                              // models.py:93
+    const float vx = (float)x - delta;                        // :45
+    const float gx = (2.0f * vx) * rw - 1.0f;                 // :47
+    const float ix = ((gx + 1.0f) / 2.0f) * fw1;              // grid_sample un-normalise
+    const float fx0 = floorf(ix), fx1 = fx0 + 1.0f;
+    wx0 = fx1 - ix;
+    wx1 = ix - fx0;
+    const float cx = fx0 < -2.0f ? -2.0f : (fx0 > (float)w ? (float)w : fx0);
+    x0 = (int)cx;
+}
+
 template <int C, bool QH>
-__global__ __launch_bounds__(256) void k_volume_l1_warp(const float *__restrict__ L,
-                                                        const float *__restrict__ R,
-                                                        const float *__restrict__ prev,
-                                                        float *__restrict__ cost,
-                                                        float *__restrict__ wflow_out, int h, int w,
-                                                        int H, int W, int m, float mul_a, float mul_b,
-                                                        const float *__restrict__ plow, int ph, int pw,
-                                                        float *__restrict__ pmat)
+__global__ __launch_bounds__(WARP_TX *WARP_NW) void k_volume_l1_warp(const float *__restrict__ L,
+                                                                      const float *__restrict__ R,
+                                                                      const float *__restrict__ prev,
+                                                                      float *__restrict__ cost,
+                                                                      float *__restrict__ wflow_out, int h, int w,
+                                                                      int H, int W, int m, float mul_a, float mul_b,
+                                                                      const float *__restrict__ plow, int ph, int pw,
+                                                                      float *__restrict__ pmat, int force_gather)
 {
     // plow != nullptr: the previous stage's full-resolution map has not been materialised (no k_upsample_add launch):
     // it is evaluated on demand as upsample(plow [ph,pw]) + prev (prev = the map of the stage before it), see
     // DeferredMap.  With H == 2h, W == 2w the four taps of pixel (y,x) are exactly the 2 x 2 block (2y..2y+1,
-    // 2x..2x+1) of that map, so the k == 0 threads also write it out (pmat) -- the map is an output of the path.
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    const int k = blockIdx.y, b = blockIdx.z;
+    // 2x..2x+1) of that map, so wave 0 also writes it out (pmat) -- the map is an output of the path.
+    constexpr int CP = C + 4;                                  // LDS floats per column: conflict-free 16-byte reads
+    __shared__ float4 sR4[2 * WARP_NCMAX * CP / 4];            // [row][column][CP]
+    __shared__ float sWf[WARP_TX];
+    __shared__ int sMeta[2];                                   // xlo, columns
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * WARP_TX + lane, y = blockIdx.y, b = blockIdx.z;
+    const int nk = 2 * m - 1;
     const int64_t plane = (int64_t)h * w;
-    if (pix >= plane) return;
-    const int y = pix / w, x = pix - y * w;
+    const bool live = x < w;
     LWS_STAMPK(10, 0);
 
-    // wflow = resize(prev)[y,x] * float(h) * float32(1/H)            (models.py:119-121)
-    float wf;
+    // phase A: left features of this thread's pixel (independent of the flow: in flight beside it)
+    f2_t l2[C / 2];
     {
-        const float rh = (float)H / (float)h, rw = (float)W / (float)w;
-        int y0, y1, x0, x1;
-        float hy0, hy1, wx0, wx1;
-        src_index(y, rh, H, y0, y1, hy0, hy1);
-        src_index(x, rw, W, x0, x1, wx0, wx1);
-        const DeferredMap dm{plow != nullptr ? plow + (int64_t)b * ph * pw : nullptr, prev + (int64_t)b * H * W, ph, pw,
-                             (float)H, 1.0f / (float)(ph > 0 ? ph : 1)};
-        const int tys[4] = {y0, y0, y1, y1}, txs[4] = {x0, x1, x0, x1};
-        float q[4];
-        deferred_at_n<4>(dm, tys, txs, H, W, q);
-        const float q00 = q[0], q01 = q[1], q10 = q[2], q11 = q[3];
-        if (pmat != nullptr && k == 0) {
-            float *pm = pmat + (int64_t)b * H * W;
-            pm[(int64_t)y0 * W + x0] = q00;
-            pm[(int64_t)y0 * W + x1] = q01;
-            pm[(int64_t)y1 * W + x0] = q10;
-            pm[(int64_t)y1 * W + x1] = q11;
+        const float *Lp = L + (int64_t)b * C * plane + (int64_t)y * w + (live ? x : 0);
+#pragma unroll
+        for (int c = 0; c < C; c += 2) {
+            l2[c / 2].x = qf<QH>(Lp[(int64_t)c * plane]);
+            l2[c / 2].y = qf<QH>(Lp[(int64_t)(c + 1) * plane]);
         }
-        float top = q00 * wx0 + q01 * wx1;
-        float bot = q10 * wx0 + q11 * wx1;
-        wf = hy0 * top + hy1 * bot;
-        wf = wf * mul_a;
-        wf = wf * mul_b;
     }
-    if (wflow_out != nullptr && k == 0) wflow_out[(int64_t)b * plane + pix] = wf;
-    LWS_STAMPK(10, 1);
-
     const float rw = 1.0f / (float)(w - 1 > 1 ? w - 1 : 1);
-    const float rh = 1.0f / (float)(h - 1 > 1 ? h - 1 : 1);
-    const float fw1 = (float)(w - 1), fh1 = (float)(h - 1);
-    const float sk = (float)(k - (m - 1));
-    float delta = wf - sk;                              // models.py:93
-    float vx = (float)x - delta;                        // :45
-    float gx = (2.0f * vx) * rw - 1.0f;                 // :47
-    float gy = (2.0f * (float)y) * rh - 1.0f;           // :48
-    float ix = ((gx + 1.0f) / 2.0f) * fw1;              // grid_sample un-normalise (align_corners=True)
-    float iy = ((gy + 1.0f) / 2.0f) * fh1;
-    float fx0 = floorf(ix), fy0 = floorf(iy);
-    float fx1 = fx0 + 1.0f, fy1 = fy0 + 1.0f;
-    float w_nw = (fx1 - ix) * (fy1 - iy);
-    float w_ne = (ix - fx0) * (fy1 - iy);
-    float w_sw = (fx1 - ix) * (iy - fy0);
-    float w_se = (ix - fx0) * (iy - fy0);
-    float cx = fx0 < -2.0f ? -2.0f : (fx0 > (float)w ? (float)w : fx0);
-    float cy = fy0 < -2.0f ? -2.0f : (fy0 > (float)h ? (float)h : fy0);
-    const int x0 = (int)cx, y0 = (int)cy, x1 = x0 + 1, y1 = y0 + 1;
-    const bool vx0 = (x0 >= 0 && x0 < w), vx1 = (x1 >= 0 && x1 < w);
-    const bool vy0 = (y0 >= 0 && y0 < h), vy1 = (y1 >= 0 && y1 < h);
-    const bool south = (iy - fy0) != 0.0f;              // else w_sw == w_se == 0 exactly
-
-    const float *Lp = L + (int64_t)b * C * plane + pix;
-    const float *Rp = R + (int64_t)b * C * plane;
-    // Taps are loaded UNCONDITIONALLY from clamped addresses (an invalid tap reads element 0 and is masked below), so
-    // that all 2-4 gathers and the L load of every channel are in flight together instead of one branch per tap.
-    const bool b_nw = vy0 && vx0, b_ne = vy0 && vx1, b_sw = south && vy1 && vx0, b_se = south && vy1 && vx1;
-    const int o_nw = b_nw ? y0 * w + x0 : 0, o_ne = b_ne ? y0 * w + x1 : 0;
-    const int o_sw = b_sw ? y1 * w + x0 : 0, o_se = b_se ? y1 * w + x1 : 0;
-    float acc = 0.0f;
-    if (!south) {                                   // wave-uniform in practice (iy depends on the row only)
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float *rp = Rp + (int64_t)c * plane;
-            const float r_nw = qf<QH>(rp[o_nw]), r_ne = qf<QH>(rp[o_ne]);
-            const float l = qf<QH>(Lp[(int64_t)c * plane]);
-            float s = 0.0f;
-            if (b_nw) s = s + r_nw * w_nw;
-            if (b_ne) s = s + r_ne * w_ne;
-            acc = acc + fabsf(l - s);                    // :101
+    const float fw1 = (float)(w - 1);
+    if (wave == 0) {
+        // wflow = resize(prev)[y,x] * float(h) * float32(1/H)            (models.py:119-121)
+        float wf = 0.0f;
+        int lo = 0x7fffffff, hi = -0x7fffffff;
+        if (live) {
+            const float rh_ = (float)H / (float)h, rw_ = (float)W / (float)w;
+            int y0, y1, x0, x1;
+            float hy0, hy1, wx0, wx1;
+            src_index(y, rh_, H, y0, y1, hy0, hy1);
+            src_index(x, rw_, W, x0, x1, wx0, wx1);
+            const DeferredMap dm{plow != nullptr ? plow + (int64_t)b * ph * pw : nullptr, prev + (int64_t)b * H * W, ph, pw,
+                                 (float)H, 1.0f / (float)(ph > 0 ? ph : 1)};
+            const int tys[4] = {y0, y0, y1, y1}, txs[4] = {x0, x1, x0, x1};
+            float q[4];
+            deferred_at_n<4>(dm, tys, txs, H, W, q);
+            if (pmat != nullptr) {
+                float *pm = pmat + (int64_t)b * H * W;
+                pm[(int64_t)y0 * W + x0] = q[0];
+                pm[(int64_t)y0 * W + x1] = q[1];
+                pm[(int64_t)y1 * W + x0] = q[2];
+                pm[(int64_t)y1 * W + x1] = q[3];
+            }
+            const float top = q[0] * wx0 + q[1] * wx1;
+            const float bot = q[2] * wx0 + q[3] * wx1;
+            wf = hy0 * top + hy1 * bot;
+            wf = wf * mul_a;
+            wf = wf * mul_b;
+            if (wflow_out != nullptr) wflow_out[(int64_t)b * plane + (int64_t)y * w + x] = wf;
+            float u0, u1;
+            warp_col(wf, 0, m, x, w, rw, fw1, lo, u0, u1);
+            warp_col(wf, nk - 1, m, x, w, rw, fw1, hi, u0, u1);
+            hi += 1;
         }
-    } else {
+        sWf[lane] = wf;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float *rp = Rp + (int64_t)c * plane;
-            const float r_nw = qf<QH>(rp[o_nw]), r_ne = qf<QH>(rp[o_ne]), r_sw = qf<QH>(rp[o_sw]), r_se = qf<QH>(rp[o_se]);
-            const float l = qf<QH>(Lp[(int64_t)c * plane]);
-            float s = 0.0f;
-            if (b_nw) s = s + r_nw * w_nw;
-            if (b_ne) s = s + r_ne * w_ne;
-            if (b_sw) s = s + r_sw * w_sw;
-            if (b_se) s = s + r_se * w_se;
-            acc = acc + fabsf(l - s);                    // :101
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o));
+            hi = max(hi, __shfl_xor(hi, o));
+        }
+        if (lane == 0) {
+            sMeta[0] = lo;
+            sMeta[1] = hi - lo + 1;
         }
     }
+    __syncthreads();
+    LWS_STAMPK(10, 1);
+    const float wf = sWf[lane];
+    const int xlo = sMeta[0], ncols = sMeta[1];
+    const WarpRow row = warp_row(y, h);
+    float *out = cost + (int64_t)b * nk * plane + (int64_t)y * w + x;
+    const float *Rb = R + (int64_t)b * C * plane;
+
+    if (force_gather || ncols > WARP_NCMAX) {
+        // fallback: the taps gathered from global memory (L2), loaded UNCONDITIONALLY from clamped addresses so that all
+        // of a channel's gathers are in flight together; invalid taps are skipped as the reference's zero padding does
+        if (!live) return;
+        const int y0 = row.y0, y1 = y0 + 1;
+        const bool vy0 = (y0 >= 0 && y0 < h), vy1 = (y1 >= 0 && y1 < h);
+        for (int k = wave; k < nk; k += WARP_NW) {
+            int x0;
+            float wx0, wx1;
+            warp_col(wf, k, m, x, w, rw, fw1, x0, wx0, wx1);
+            const int x1 = x0 + 1;
+            const bool vx0 = (x0 >= 0 && x0 < w), vx1 = (x1 >= 0 && x1 < w);
+            const float w_nw = wx0 * row.wy0, w_ne = wx1 * row.wy0, w_sw = wx0 * row.wy1, w_se = wx1 * row.wy1;
+            const bool b_nw = vy0 && vx0, b_ne = vy0 && vx1, b_sw = row.south && vy1 && vx0, b_se = row.south && vy1 && vx1;
+            const int o_nw = b_nw ? y0 * w + x0 : 0, o_ne = b_ne ? y0 * w + x1 : 0;
+            const int o_sw = b_sw ? y1 * w + x0 : 0, o_se = b_se ? y1 * w + x1 : 0;
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float *rp = Rb + (int64_t)c * plane;
+                const float r_nw = qf<QH>(rp[o_nw]), r_ne = qf<QH>(rp[o_ne]);
+                float r_sw = 0.0f, r_se = 0.0f;
+                if (row.south) {
+                    r_sw = qf<QH>(rp[o_sw]);
+                    r_se = qf<QH>(rp[o_se]);
+                }
+                const float l = (c & 1) ? l2[c / 2].y : l2[c / 2].x;
+                float s = 0.0f;
+                if (b_nw) s = s + r_nw * w_nw;
+                if (b_ne) s = s + r_ne * w_ne;
+                if (b_sw) s = s + r_sw * w_sw;
+                if (b_se) s = s + r_se * w_se;
+                acc = acc + fabsf(l - s);                    // :101
+            }
+            out[(int64_t)k * plane] = acc;
+        }
+        return;
+    }
+
+    // phase B: stage the window.  item = (column, 4-channel group): four coalesced plane loads, one 16-byte LDS write
+    {
+        const int nrows = row.south ? 2 : 1;
+        const int per_row = ncols * (C / 4);
+        for (int it = threadIdx.x; it < nrows * per_row; it += WARP_TX * WARP_NW) {
+            const int r = it >= per_row ? 1 : 0;
+            const int i = it - r * per_row;
+            const int cg = i / ncols, col = i - cg * ncols;
+            const int xg = xlo + col, yr = row.y0 + r;
+            const bool ok = xg >= 0 && xg < w && yr >= 0 && yr < h;
+            const float *rp = Rb + (int64_t)(4 * cg) * plane + (ok ? yr * w + xg : 0);
+            float4 v;
+            v.x = rp[0];
+            v.y = rp[plane];
+            v.z = rp[2 * plane];
+            v.w = rp[3 * plane];
+            if (ok) {
+                v.x = qf<QH>(v.x);
+                v.y = qf<QH>(v.y);
+                v.z = qf<QH>(v.z);
+                v.w = qf<QH>(v.w);
+            } else {
+                v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            sR4[((r * WARP_NCMAX + col) * CP + 4 * cg) / 4] = v;
+        }
+    }
+    __syncthreads();
     LWS_STAMPK(10, 2);
-    cost[((int64_t)b * (2 * m - 1) + k) * plane + pix] = acc;
+    if (!live) return;
+
+    // phase C
+    for (int k = wave; k < nk; k += WARP_NW) {
+        int x0;
+        float wx0, wx1;
+        warp_col(wf, k, m, x, w, rw, fw1, x0, wx0, wx1);
+        const float w_nw = wx0 * row.wy0, w_ne = wx1 * row.wy0;
+        const float4 *p0 = sR4 + ((x0 - xlo) * CP) / 4;        // column x0, row y0; column x0 + 1 follows CP floats later
+        const f2_t Wnw = {w_nw, w_nw}, Wne = {w_ne, w_ne};
+        float acc = 0.0f;
+        if (!row.south) {
+#pragma unroll
+            for (int cg = 0; cg < C / 4; ++cg) {
+                const float4 a = p0[cg], e = p0[CP / 4 + cg];
+                const f2_t a0 = {a.x, a.y}, a1 = {a.z, a.w}, e0 = {e.x, e.y}, e1 = {e.z, e.w};
+                const f2_t s0 = a0 * Wnw + e0 * Wne, s1 = a1 * Wnw + e1 * Wne;
+                const f2_t d0 = l2[2 * cg] - s0, d1 = l2[2 * cg + 1] - s1;
+                acc = acc + fabsf(d0.x);                     // :101, channels ascending
+                acc = acc + fabsf(d0.y);
+                acc = acc + fabsf(d1.x);
+                acc = acc + fabsf(d1.y);
+            }
+        } else {
+            const float w_sw = wx0 * row.wy1, w_se = wx1 * row.wy1;
+            const f2_t Wsw = {w_sw, w_sw}, Wse = {w_se, w_se};
+            const float4 *p1 = p0 + (WARP_NCMAX * CP) / 4;
+#pragma unroll
+            for (int cg = 0; cg < C / 4; ++cg) {
+                const float4 a = p0[cg], e = p0[CP / 4 + cg], f = p1[cg], g = p1[CP / 4 + cg];
+                const f2_t a0 = {a.x, a.y}, a1 = {a.z, a.w}, e0 = {e.x, e.y}, e1 = {e.z, e.w};
+                const f2_t f0 = {f.x, f.y}, f1 = {f.z, f.w}, g0 = {g.x, g.y}, g1 = {g.z, g.w};
+                const f2_t s0 = ((a0 * Wnw + e0 * Wne) + f0 * Wsw) + g0 * Wse;
+                const f2_t s1 = ((a1 * Wnw + e1 * Wne) + f1 * Wsw) + g1 * Wse;
+                const f2_t d0 = l2[2 * cg] - s0, d1 = l2[2 * cg + 1] - s1;
+                acc = acc + fabsf(d0.x);
+                acc = acc + fabsf(d0.y);
+                acc = acc + fabsf(d1.x);
+                acc = acc + fabsf(d1.y);
+            }
+        }
+        out[(int64_t)k * plane] = acc;
+    }
     LWS_STAMPK(10, 3);
 }
 
 int launch_volume_l1_warp(const float *L, const float *R, const float *prev, float *cost, float *wflow_out,
                           int B, int C, int h, int w, int H, int W, int m, hipStream_t st, bool q16, const float *plow,
-                          int ph, int pw, float *pmat)
+                          int ph, int pw, float *pmat, int form)
 {
     if (pmat != nullptr && (plow == nullptr || H != 2 * h || W != 2 * w)) {
         set_error("volume_l1_warp: the deferred map can only be written out at exactly half resolution");
         return LWS_ERR_INVALID;
     }
-    dim3 grid(cdiv(h * w, 256), 2 * m - 1, B), block(256);
+    dim3 grid(cdiv(w, WARP_TX), h, B), block(WARP_TX * WARP_NW);
     const float mul_a = (float)h, mul_b = 1.0f / (float)H;
+    const int force_gather = form == 0 ? 1 : 0;
 #define LWS_VW(CC)                                                                                                   \
     if (q16)                                                                                                          \
         hipLaunchKernelGGL((k_volume_l1_warp<CC, true>), grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m,  \
-                           mul_a, mul_b, plow, ph, pw, pmat);                                                                             \
+                           mul_a, mul_b, plow, ph, pw, pmat, force_gather);                                               \
     else                                                                                                              \
         hipLaunchKernelGGL((k_volume_l1_warp<CC, false>), grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m, \
-                           mul_a, mul_b, plow, ph, pw, pmat)
+                           mul_a, mul_b, plow, ph, pw, pmat, force_gather)
     switch (C) {
         case 8: LWS_VW(8); break;
         case 16: LWS_VW(16); break;

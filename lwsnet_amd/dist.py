@@ -18,10 +18,41 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init_from_env(backend=None):
+# ---- root-rank budget of the ONE collective (measured on one MI355X with the root's inbound volume
+# emulated: tools/gather_probe.py --beside --emulate-world 8, profiles/r04/gather_root_emulation.txt) ---------------------
+# RCCL's send/recv kernel runs on the compute units beside the forward.  What it costs the root is set by (a) how many
+# channels (workgroups) RCCL gives it -- read from the environment when the communicator is created -- and (b) how many bytes
+# one gather writes on the root, i.e. world x pairs-per-rank-per-gather x H*W*4.  The policy below is a function of the world
+# size; callers' own NCCL_* settings win (setdefault).
+GATHER_POLICY = {
+    # world: (channel cap, minimum pairs per rank per gather for 1-pair steps)
+    1: (None, 8),
+    2: (None, 8),
+    4: (None, 8),
+    8: (None, 8),
+}
+
+
+def gather_policy(world):
+    """(channel cap or None, minimum pairs per rank carried by one gather) for a job of `world` ranks."""
+    key = max(k for k in GATHER_POLICY if k <= max(1, int(world)))
+    return GATHER_POLICY[key]
+
+
+def apply_channel_cap(world):
+    """Exports RCCL's channel caps for a `world`-rank job unless the caller set them; must run before the communicator exists."""
+    cap, _ = gather_policy(world)
+    if cap is not None:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(cap))
+        os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", str(cap))
+    return cap
+
+
+def init_from_env(backend=None, tune=True):
     """Initialise the default process group from torchrun's environment.  Without that environment (plain
     `python bench.py`) this is a no-op; under torchrun a world of ONE is initialised too, so that a single GPU runs the
-    same RCCL code path (communicator set-up, gather, barrier) the N-GPU job runs."""
+    same RCCL code path (communicator set-up, gather, barrier) the N-GPU job runs.  `tune`: apply gather_policy's channel
+    cap for this world size first (tools/gather_probe.py passes False to measure RCCL's own defaults)."""
     rank, local_rank, world = env_rank()
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if launched and not dist.is_initialized():
@@ -31,6 +62,8 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
         if backend == "nccl":
+            if tune:
+                apply_channel_cap(world)
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
@@ -81,9 +114,13 @@ class StagedGather:
     gather to rank `dst` when the buffer is full.  Two staging buffers alternate: the gather of one overlaps the steps that
     fill the other.  `flush()` gathers a partly filled buffer (the tail) and waits for everything in flight.
     Rank `dst` reads the gathered maps of rank r, gather g (0 = most recent completed) from `gathered(r)`.
-    Measured r03 on one MI355X under torchrun: one gather per 0.5 ms step costs ~9 % of the step, one per 8 steps ~2 %."""
 
-    def __init__(self, B, H, W, group, device, dtype=torch.float32, dst=0):
+    With `multi_stream=True` steps may run on DIFFERENT streams (bench.py --streams N): `commit()` records an event on the stream that produced the
+    slot and the gather is ordered behind every slot's event; `slot()` makes the current stream wait until the previous
+    gather out of the buffer it hands out has completed (the gather used to be ordered behind the last
+    committing stream only)."""
+
+    def __init__(self, B, H, W, group, device, dtype=torch.float32, dst=0, multi_stream=False):
         self.B, self.group, self.dst = int(B), max(1, int(group)), dst
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
@@ -94,13 +131,25 @@ class StagedGather:
         self.pending = [None, None]
         self.buf, self.fill, self.count = 0, 0, 0
         self.last = None                      # (buffer, slots filled) of the most recent gather
+        self.on_gpu = bool(multi_stream) and torch.device(device).type == "cuda"   # events only when steps use several streams
+        self.slot_events = [[], []]           # per staging buffer: (stream, event) of every committed slot
+        self.free_event = [None, None]        # per staging buffer: recorded once its previous gather has completed
 
     def slot(self):
-        """Destination [B,1,H,W] for this step's stage-4 map."""
+        """Destination [B,1,H,W] for this step's stage-4 map (valid on the CURRENT stream)."""
+        ev = self.free_event[self.buf]
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
         return self.staging[self.buf][self.fill * self.B:(self.fill + 1) * self.B]
 
     def _issue(self):
         b = self.buf
+        if self.on_gpu:
+            cur = torch.cuda.current_stream()
+            for st, ev in self.slot_events[b]:
+                if st != cur:
+                    cur.wait_event(ev)
+            self.slot_events[b] = []
         if dist.is_initialized():
             self.pending[b] = gather_async(self.staging[b], self.recv[b], dst=self.dst)
         else:
@@ -111,9 +160,16 @@ class StagedGather:
         if self.pending[1 - b] is not None:   # the buffer the next steps write into: its gather must have finished
             self.pending[1 - b].wait()        # (a stream-side wait on the NCCL backend, not a host block)
             self.pending[1 - b] = None
+            if self.on_gpu:                   # ... and steps on other streams learn about it through this event
+                self.free_event[1 - b] = torch.cuda.Event()
+                self.free_event[1 - b].record()
 
     def commit(self):
-        """Call after the forward that wrote slot(); returns True when this step triggered a gather."""
+        """Call after the forward that wrote slot(), on the same stream; returns True when this step triggered a gather."""
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.slot_events[self.buf].append((torch.cuda.current_stream(), ev))
         self.fill += 1
         if self.fill == self.group:
             self._issue()

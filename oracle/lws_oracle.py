@@ -21,6 +21,79 @@ import torch.nn.functional as F
 
 EPS = 1e-5
 
+# ---- the op defaults this restatement BETS on (from memory of Paddle 2.0, not verifiable offline), kept
+# as switches so that the size of each bet can be measured (tools/oracle_sensitivity.py, profiles/r04/oracle_sensitivity.txt).
+# The first value of each line is the default = what every parity test and the C oracle / HIP kernels implement.
+#   align_mode   0: F.interpolate(bilinear, align_corners=False) samples at half-pixel centres, src = ratio*(dst+0.5)-0.5
+#                1: Paddle 1.x / 2.0-beta default, src = ratio*dst
+#   grid_unnorm  "cuda": grid_sample un-normalises as ((g+1)/2)*(size-1)   (Paddle's CUDA kernel, torch)
+#                "cpu":  (g+1)*((size-1)*0.5)                                 (Paddle's CPU kernel)
+#   scalar_div   "reciprocal": tensor / python_scalar is a scale op by fp32(1/c)
+#                "divide":     a true elementwise division
+VARIANT = {"align_mode": 0, "grid_unnorm": "cuda", "scalar_div": "reciprocal"}
+
+
+class variant:
+    """with variant(align_mode=1): ...  -- run the restatement under another reading of Paddle's defaults."""
+
+    def __init__(self, **kw):
+        unknown = set(kw) - set(VARIANT)
+        if unknown:
+            raise KeyError(f"unknown oracle variant switch(es): {sorted(unknown)}")
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = dict(VARIANT)
+        VARIANT.update(self.kw)
+        return self
+
+    def __exit__(self, *a):
+        VARIANT.clear()
+        VARIANT.update(self.saved)
+
+
+def interp_bilinear(x, size, align_mode=0):
+    """Paddle's bilinear F.interpolate with align_corners=False.  align_mode 0 = half-pixel centres (torch's
+    align_corners=False); align_mode 1 = src = ratio * dst (clamped taps), written out separably."""
+    if align_mode == 0:
+        return F.interpolate(x, size=list(size), mode="bilinear", align_corners=False)
+
+    def axis(n_in, n_out):
+        ratio = torch.tensor(float(n_in), dtype=x.dtype) / torch.tensor(float(n_out), dtype=x.dtype)
+        src = ratio * torch.arange(n_out, dtype=x.dtype)
+        i0 = src.floor().clamp(max=n_in - 1)
+        lam = src - i0
+        i0 = i0.long()
+        i1 = (i0 + 1).clamp(max=n_in - 1)
+        return i0, i1, lam
+
+    y0, y1, ly = axis(x.shape[2], size[0])
+    x0, x1, lx = axis(x.shape[3], size[1])
+    top = x[:, :, y0][:, :, :, x0] * (1 - lx) + x[:, :, y0][:, :, :, x1] * lx
+    bot = x[:, :, y1][:, :, :, x0] * (1 - lx) + x[:, :, y1][:, :, :, x1] * lx
+    return top * (1 - ly)[:, None] + bot * ly[:, None]
+
+
+def grid_sample_bilinear(x, grid, unnorm="cuda"):
+    """F.grid_sample(bilinear, zeros, align_corners=True).  "cuda" is torch's own kernel; "cpu" re-derives the pixel
+    coordinates as (g+1)*((size-1)*0.5) and gathers the four taps (nw, ne, sw, se summed in that order)."""
+    if unnorm == "cuda":
+        return F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    B, C, H, W = x.shape
+    ix = (grid[..., 0] + 1.0) * ((W - 1) * 0.5)
+    iy = (grid[..., 1] + 1.0) * ((H - 1) * 0.5)
+    x0, y0 = ix.floor(), iy.floor()
+    x1, y1 = x0 + 1, y0 + 1
+    flat = x.reshape(B, C, H * W)
+    out = torch.zeros((B, C) + tuple(ix.shape[1:]), dtype=x.dtype)
+    for xs, ys, wgt in ((x0, y0, (x1 - ix) * (y1 - iy)), (x1, y0, (ix - x0) * (y1 - iy)),
+                        (x0, y1, (x1 - ix) * (iy - y0)), (x1, y1, (ix - x0) * (iy - y0))):
+        ok = (xs >= 0) & (xs <= W - 1) & (ys >= 0) & (ys <= H - 1)
+        idx = (ys.clamp(0, H - 1) * W + xs.clamp(0, W - 1)).long().reshape(B, 1, -1).expand(B, C, -1)
+        tap = flat.gather(2, idx).reshape(out.shape)
+        out = out + tap * (wgt * ok.to(x.dtype)).unsqueeze(1)
+    return out
+
 
 def _t(sd, key, dtype):
     return torch.as_tensor(np.asarray(sd[key]), dtype=dtype)
@@ -36,6 +109,8 @@ def _bn(x, sd, prefix, dtype):
 def _scale(x, c, dtype):
     """Paddle lowers ``tensor / python_scalar`` to a scale op by the reciprocal
     (SURVEY.md appendix B); the reciprocal is rounded to the tensor dtype."""
+    if VARIANT["scalar_div"] == "divide":
+        return x / torch.tensor(float(c), dtype=dtype)
     r = torch.tensor(1.0, dtype=dtype) / torch.tensor(float(c), dtype=dtype)
     return x * r
 
@@ -91,7 +166,7 @@ def warp(x, disp, dtype=torch.float32):
     vgrid[:, 0] = _scale(2.0 * vgrid[:, 0], max(W - 1, 1), dtype) - 1.0
     vgrid[:, 1] = _scale(2.0 * vgrid[:, 1], max(H - 1, 1), dtype) - 1.0
     vgrid = vgrid.permute(0, 2, 3, 1)
-    return F.grid_sample(x, vgrid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    return grid_sample_bilinear(x, vgrid, VARIANT["grid_unnorm"])
 
 
 def build_volume_2d(feat_l, feat_r, maxdisp, dtype=torch.float32):
@@ -141,8 +216,8 @@ def disparity_regression(prob, start, end, dtype=torch.float32):
 
 
 def _interp(x, size):
-    # F.interpolate(mode="bilinear"): align_corners=False, align_mode=0 (half-pixel)
-    return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    # F.interpolate(mode="bilinear"): align_corners=False, align_mode=0 (half-pixel) unless VARIANT says otherwise
+    return interp_bilinear(x, size, VARIANT["align_mode"])
 
 
 def disparity_stages(feats_l, feats_r, H, W, sd, maxdisplist, dtype=torch.float32, return_costs=False):

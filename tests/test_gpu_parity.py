@@ -65,21 +65,33 @@ def test_volume_shift_rejects_narrow_input(dev, hip_lib):
 
 
 # ------------------------------------------------------------------ K2
-def _warp_case(rng, B, C, h, w, scale):
+def _warp_case(rng, B, C, h, w, scale, wild=0.0):
+    """Flows that ramp from +0.35 W to -0.15 W (taps left and right of the image) plus noise; `wild` > 0 adds, to every
+    other band of 8 rows, blocks whose flow jumps by up to +-wild full-resolution pixels: the column window of such a row
+    segment exceeds the LDS window of k_volume_l1_warp and the workgroup takes its gather fallback (both forms in one launch)."""
     H, W = h * scale, w * scale
     L = rng.standard_normal((B, C, h, w)).astype(np.float32)
     R = rng.standard_normal((B, C, h, w)).astype(np.float32)
     ramp = 0.35 * W - 0.5 * W * np.arange(W, dtype=np.float64)[None, None, None, :] / W
-    prev = (ramp + rng.random((B, 1, H, W)) * 6.0).astype(np.float32)
-    return L, R, prev, H, W
+    prev = ramp + rng.random((B, 1, H, W)) * 6.0
+    if wild > 0:
+        jump = (rng.random((B, 1, H // 8 + 1, W // 16 + 1)) * 2.0 - 1.0) * wild
+        jump[:, :, 1::2] = 0.0
+        prev = prev + np.repeat(np.repeat(jump, 8, axis=2), 16, axis=3)[:, :, :H, :W]
+    return L, R, prev.astype(np.float32), H, W
 
 
-@pytest.mark.parametrize("B,C,h,w,scale,m", [(1, 16, 16, 64, 4, 5), (2, 16, 46, 78, 4, 5), (1, 8, 64, 128, 2, 5),
-                                             (2, 8, 34, 50, 2, 3)])
-def test_volume_warp_bitexact(dev, hip_lib, B, C, h, w, scale, m):
+@pytest.mark.parametrize("B,C,h,w,scale,m,wild", [(1, 16, 16, 64, 4, 5, 0), (2, 16, 46, 78, 4, 5, 0), (1, 8, 64, 128, 2, 5, 0),
+                                                  (2, 8, 34, 50, 2, 3, 0), (2, 8, 40, 300, 2, 5, 700.0), (1, 16, 24, 333, 4, 5, 2000.0),
+                                                  (1, 8, 3, 1, 2, 5, 0), (1, 16, 1, 7, 4, 2, 0), (2, 8, 19, 65, 2, 1, 0),
+                                                  (1, 16, 30, 200, 4, 9, 900.0)])
+def test_volume_warp_bitexact(dev, hip_lib, B, C, h, w, scale, m, wild):
+    """k_volume_l1_warp against the C oracle, bit for bit: flows that leave the image on both sides, ragged widths (a last
+    row segment of 1 pixel), single-column / single-row maps, m from 1 (one hypothesis) to 9, and -- `wild` -- row segments
+    whose flow range forces the workgroup-uniform gather fallback beside segments that take the LDS window."""
     from lwsnet_amd import ops
     from oracle import c_oracle as C_
-    L, R, prev, H, W = _warp_case(np.random.default_rng(5), B, C, h, w, scale)
+    L, R, prev, H, W = _warp_case(np.random.default_rng(5), B, C, h, w, scale, wild)
     cost, wflow = ops.volume_l1_warp(cu(L, dev), cu(R, dev), cu(prev, dev), m, return_wflow=True)
     wf = C_.resize_bilinear(prev[:, 0], h, w, float(h), float(np.float32(1) / np.float32(H)))
     assert_bits(wflow, wf, "wflow")
@@ -342,6 +354,7 @@ OPTION_PLANS = [{"left_at": 0}, {"left_at": 2}, {"split_heads": 1}, {"split_head
                 {"fuse_first": 0}, {"defer_upsample": 0}, {"mid8_form": 1}, {"mid8_form": 0},
                 {"conv3d_order": 1}, {"conv3d_order": 0}, {"ref_chunk_mb": 0}, {"ref_chunk_mb": 1},
                 {"side_streams": 0}, {"side_streams": 0, "left_at": 0}, {"left_at": 2, "split_heads": 1},
+                {"warp_form": 0}, {"warp_form": 0, "defer_upsample": 0},
                 {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0, "mid8_form": 1}]
 
 

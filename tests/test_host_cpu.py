@@ -29,6 +29,84 @@ def test_pdparams_roundtrip_and_restricted_unpickler(tmp_path, state_dict):
                           state_dict["refinement2.5.weight"])
 
 
+def _paddle_names(state_dict):
+    """Paddle's internal parameter names for the reference's layer tree, as dygraph's unique-name generator hands them out
+    in construction order: conv2d_N.w_0, batch_norm_N.w_0 / .b_0 / .w_1 (_mean) / .w_2 (_variance), conv3d_N.w_0, ..."""
+    counters, owner, table = {}, {}, {}
+    for key in state_dict:
+        layer, leaf = key.rsplit(".", 1)
+        if layer not in owner:
+            v = np.asarray(state_dict[key])
+            kind = ("batch_norm" if leaf in ("weight", "bias", "_mean", "_variance") and v.ndim == 1 else
+                    "conv3d" if v.ndim == 5 else "conv2d_transpose" if ".conv5." in key or ".conv6." in key else "conv2d")
+            owner[layer] = f"{kind}_{counters.setdefault(kind, 0)}"
+            counters[kind] += 1
+        table[key] = owner[layer] + {"weight": ".w_0", "bias": ".b_0", "_mean": ".w_1", "_variance": ".w_2"}[leaf]
+    return table
+
+
+def test_pdparams_as_paddle_2_0rc0_writes_it(tmp_path, state_dict):
+    """`paddle.save(model.state_dict(), path)` in 2.0.0rc0 (train.py:115): `_build_saved_state_dict` turns every VarBase into
+    `value.numpy()`, collects `{structured name: value.name}` under "StructuredToParameterName@@" and pickles the dict with
+    protocol 2.  Built here by hand (not with checkpoint.save_pdparams), including the internal parameter names, an
+    OrderedDict container and non-contiguous / float64 arrays a user-side conversion might leave behind."""
+    import collections
+    saved = collections.OrderedDict()
+    for i, (k, v) in enumerate(state_dict.items()):
+        a = np.asarray(v)
+        saved[k] = np.asfortranarray(a) if i % 7 == 0 else (a.astype(np.float64) if i % 11 == 0 else a)
+    saved["StructuredToParameterName@@"] = _paddle_names(state_dict)
+    with open(tmp_path / "rc0.pdparams", "wb") as f:
+        pickle.dump(saved, f, protocol=2)
+    sd = checkpoint.load_state_dict(tmp_path / "rc0.pdparams")
+    assert list(sd) == list(state_dict) and len(sd) == 226
+    for k in sd:
+        assert sd[k].dtype == np.float32 and sd[k].flags["C_CONTIGUOUS"] and np.array_equal(sd[k], state_dict[k]), k
+    # 2.0 final writes an (empty) big-parameter table when nothing was split; a non-empty one is refused, not mis-read
+    saved["UnpackBigParamInfor@@"] = {}
+    with open(tmp_path / "v20.pdparams", "wb") as f:
+        pickle.dump(dict(saved), f, protocol=2)
+    assert set(checkpoint.load_state_dict(tmp_path / "v20.pdparams")) == set(state_dict)
+    saved["UnpackBigParamInfor@@"] = {"refinement2.5.weight": {"OriginShape": (1, 32, 3, 3), "slices": ["a", "b"]}}
+    with open(tmp_path / "split.pdparams", "wb") as f:
+        pickle.dump(dict(saved), f, protocol=2)
+    with pytest.raises(ValueError, match="split"):
+        checkpoint.load_state_dict(tmp_path / "split.pdparams")
+
+
+def test_pdparams_as_paddle_2_1_writes_it(tmp_path, state_dict):
+    """Paddle >= 2.1 (`paddle.save` -> `_pickle_save` with `reduce_varbase`): each tensor is pickled as the tuple
+    (internal parameter name, ndarray), protocol 4 by default, and there is no name table."""
+    names = _paddle_names(state_dict)
+    saved = {k: (names[k], np.asarray(v)) for k, v in state_dict.items()}
+    for proto in (2, 4):
+        p = tmp_path / f"v21_p{proto}.pdparams"
+        with open(p, "wb") as f:
+            pickle.dump(saved, f, protocol=proto)
+        sd = checkpoint.load_state_dict(p)
+        assert list(sd) == list(state_dict)
+        assert all(np.array_equal(sd[k], state_dict[k]) and sd[k].dtype == np.float32 for k in sd)
+    # integer arrays, non-string keys and objects are refused with a ValueError / UnpicklingError, never executed
+    for bad, exc in (({"w": np.arange(4)}, ValueError), ({3: np.zeros(2, np.float32)}, ValueError),
+                     ({"w": ("n", [1.0, 2.0])}, ValueError), ({"w": np.zeros(2, np.float32), "x@@": 3}, ValueError)):
+        with open(tmp_path / "bad.pdparams", "wb") as f:
+            pickle.dump(bad, f, protocol=2)
+        with pytest.raises(exc):
+            checkpoint.load_state_dict(tmp_path / "bad.pdparams")
+
+
+def test_pdparams_loads_into_the_model_spec(tmp_path, state_dict):
+    """A checkpoint in the 2.0rc0 layout passes the library's own key / shape check (lws_set_tensor's spec is derived from
+    the constructor arguments exactly as the reference's layer tree is): every one of the 226 tensors is accepted."""
+    import collections
+    from lwsnet_amd.weights import default_args, state_dict_spec
+    checkpoint.save_pdparams(state_dict, tmp_path / "m.pdparams")
+    sd = checkpoint.load_state_dict(tmp_path / "m.pdparams")
+    spec = {k: shape for k, shape, _ in state_dict_spec(default_args())}
+    assert sorted(sd) == sorted(spec) and len(spec) == 226
+    assert all(tuple(sd[k].shape) == tuple(spec[k]) for k in spec)
+
+
 def test_crop_and_normalise_follow_inference_py():
     img = np.arange(375 * 1242 * 3, dtype=np.uint32).reshape(375, 1242, 3).astype(np.uint8)
     c = imageio.crop_bottom_right(img)

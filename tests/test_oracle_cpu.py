@@ -201,3 +201,34 @@ def test_synth_pair_is_seeded_and_valid():
     assert np.array_equal(l, l2) and np.array_equal(r, r2)
     assert l.shape == (3, 64, 256) and l.dtype == np.float32
     assert 0 < g.min() and g.max() < 192
+
+
+def test_oracle_variant_switches(state_dict):
+    """The three readings of Paddle's defaults the restatement bets on are switches; the default is
+    what every fixture was generated with, a variant is restored on exit, and the alternative kernels are right where they can be
+    checked independently: align_mode=1 on an integer down-scale picks pixel ratio*dst exactly, and the "cpu"
+    un-normalisation equals torch's own grid_sample in float64 (where the two forms agree to rounding)."""
+    assert O.VARIANT == {"align_mode": 0, "grid_unnorm": "cuda", "scalar_div": "reciprocal"}
+    x = torch.arange(2 * 8 * 12, dtype=torch.float64).reshape(1, 2, 8, 12)
+    assert torch.equal(O.interp_bilinear(x, [4, 6], 1), x[:, :, ::2, ::2])
+    assert torch.equal(O.interp_bilinear(x, [8, 12], 1), x)
+    up = O.interp_bilinear(x[:, :, :2, :2], [4, 4], 1)                      # src = 0, .5, 1, 1.5 -> taps (0,1) and clamped (1,1)
+    assert torch.allclose(up[0, 0, 0], torch.tensor([0.0, 0.5, 1.0, 1.0], dtype=torch.float64))
+    g = torch.rand((1, 5, 7, 2), dtype=torch.float64) * 2.4 - 1.2          # taps inside and outside the image
+    a = O.grid_sample_bilinear(x, g, "cuda")
+    b = O.grid_sample_bilinear(x, g, "cpu")
+    assert torch.allclose(a, b, rtol=0, atol=1e-9)
+    left, right, _ = make_pair(64, 256, 0)
+    base = O.forward(left[None], right[None], state_dict)
+    with O.variant(grid_unnorm="cpu", scalar_div="divide"):
+        assert O.VARIANT["grid_unnorm"] == "cpu"
+        alt = O.forward(left[None], right[None], state_dict)
+    assert O.VARIANT == {"align_mode": 0, "grid_unnorm": "cuda", "scalar_div": "reciprocal"}
+    assert torch.equal(alt[0], base[0])                                     # stage 1 uses neither op
+    d = float((alt[3] - base[3]).abs().max())
+    assert 0.0 < d < 5e-3, d                                                # last-ulp readings: below the float32 noise floor
+    with O.variant(align_mode=1):
+        shifted = O.forward(left[None], right[None], state_dict)
+    assert float((shifted[0] - base[0]).abs().max()) > 1.0                  # a different function, not a rounding difference
+    with pytest.raises(KeyError):
+        O.variant(no_such_switch=1)

@@ -58,6 +58,9 @@ class Tensor(torch.Tensor):
     # -- scalar arithmetic --------------------------------------------------------------------
     def __truediv__(self, other):
         if _is_scalar(other):
+            from oracle import lws_oracle as O
+            if O.VARIANT["scalar_div"] == "divide":              # the other reading: a true elementwise division
+                return torch.Tensor.__truediv__(self, torch.tensor(float(other), dtype=self.dtype))
             r = torch.tensor(1.0, dtype=self.dtype) / torch.tensor(float(other), dtype=self.dtype)
             return torch.Tensor.__mul__(self, r)
         return torch.Tensor.__truediv__(self, other)
@@ -275,13 +278,20 @@ def softmax(x, axis=-1):
     return Tensor.wrap(TF.softmax(x, dim=axis))
 
 
-def interpolate(x, size=None, mode="nearest", align_corners=False, align_mode=0):
-    assert mode == "bilinear" and align_corners is False and align_mode == 0
-    return Tensor.wrap(TF.interpolate(x, size=list(size), mode="bilinear", align_corners=False))
+# The stand-in's readings of Paddle's defaults are the SAME switches as the restatement's (oracle.lws_oracle.VARIANT:
+# align_mode, grid_unnorm, scalar_div) and share its implementations, so tools/oracle_sensitivity.py can run the reference's
+# own source under each reading.
+def interpolate(x, size=None, mode="nearest", align_corners=False, align_mode=None):
+    from oracle import lws_oracle as O
+    assert mode == "bilinear" and align_corners is False
+    am = O.VARIANT["align_mode"] if align_mode is None else align_mode      # (the reference never passes align_mode)
+    return Tensor.wrap(O.interp_bilinear(x, list(size), am))
 
 
 def grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=True):
-    return Tensor.wrap(TF.grid_sample(x, grid, mode=mode, padding_mode=padding_mode, align_corners=align_corners))
+    from oracle import lws_oracle as O
+    assert mode == "bilinear" and padding_mode == "zeros" and align_corners is True
+    return Tensor.wrap(O.grid_sample_bilinear(x, grid, O.VARIANT["grid_unnorm"]))
 
 
 def install():
