@@ -49,22 +49,23 @@ def _sha256(path):
         return hashlib.sha256(f.read()).hexdigest()
 
 
-def _with_traffic(roof, B):
-    """roofline.traffic: HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary
-    (profiles/r*/pmc_fetch_write_b1_256x512.json: separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside this process, so the number is
-    only reported when (a) the workload is the B=1 one it was collected on and (b) the summary records the sha256 of
-    lwsnet_amd/csrc/lws_conv3d.hip it was collected with and that still matches the source in this tree; otherwise
-    traffic stays null and traffic_note says why."""
+def _with_traffic(roof, B, H, W, maxdisp0, fp16):
+    """roofline.traffic: HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary OF THIS
+    WORKLOAD (profiles/r*/pmc_fetch_write_b<B>_<H>x<W>.json, written by tools/pmc_summary.py from separate FETCH_SIZE /
+    WRITE_SIZE passes, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside this
+    process, so the number is only reported when (a) a summary exists for exactly this batch, size and maxdisplist and (b) it
+    records the sha256 of lwsnet_amd/csrc/lws_conv3d.hip it was collected with and that still matches the source in this
+    tree; otherwise traffic stays null and traffic_note says why."""
     if roof is None:
         return roof
-    if B != 1:
-        roof["traffic_note"] = "null: the committed PMC summary was collected at batch 1"
+    if maxdisp0 != 24 or fp16:
+        roof["traffic_note"] = "null: no PMC summary was collected for this maxdisplist / feature precision"
         return roof
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_fetch_write_b1_256x512.json")))
+    tag = f"b{B}_{H}x{W}"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_fetch_write_{tag}.json")))
     if not files:
-        roof["traffic_note"] = "null: no PMC summary under profiles/"
+        roof["traffic_note"] = f"null: no PMC summary for this workload under profiles/ (pmc_fetch_write_{tag}.json)"
         return roof
     try:
         with open(files[-1]) as f:
@@ -174,7 +175,8 @@ def main():
     ap.add_argument("--feature-fp16", action="store_true", help="BASELINE config 5: fp16-rounded feature maps")
     ap.add_argument("--maxdisp0", type=int, default=24, help="stage-1 hypotheses (24 = maxdisp 192, 32 = maxdisp 256)")
     ap.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed forwards before the warm-up steps (clock ramp of an idle GPU)")
-    ap.add_argument("--gather-pairs", type=int, default=8, help="minimum pairs per rank carried by one RCCL gather (staged gather)")
+    ap.add_argument("--gather-pairs", type=int, default=None,
+                    help="minimum pairs per rank carried by one RCCL gather (staged gather); default: lwsnet_amd.dist.gather_policy(world size)")
     ap.add_argument("--opt", action="append", default=[], help="name=value launch-plan option (lws_set_option); experiments only")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check without a GPU: gloo, per-pair stand-in forward, value = null (tests only)")
@@ -219,16 +221,15 @@ def main():
 
     grouped = dist.is_initialized()                      # torchrun launch (any world size, also 1): run the collective
     # The ONE collective of the path: stage-4 maps -> rank 0 (north_star: "a single RCCL gather for
-    # the output disparities" of a batch).  A gather carries at least 8 pairs per rank (4 MB at 256x512: what BASELINE config 4
-    # gathers per rank): with 1 pair per step the stage-4 maps of 8 consecutive steps are written straight into the slots of a
-    # staging buffer (lws_forward's output pointer) and gathered together (lwsnet_amd.dist.StagedGather).  Measured r03 on
-    # one MI355X under torchrun with 8 hardware queues (tools/gather_probe.py, profiles/r03/experiments/gather_overhead.txt):
-    # an isolated gather completes in ~46 us whatever its size (host call 25-30 us), but beside a running forward it delays
-    # the step by ~30 / 80 / 140 / 1,000 us at 0.5 / 2 / 4 / 8 MB (RCCL's send/recv kernel shares the CUs and takes more
-    # channels for larger messages): 5.9-7.8 % of a 0.5 ms step with a gather per step, 3.6-4.1 % with 4 or 8 pairs per gather,
-    # 14-18 % with 16.  Two staging buffers alternate, so the asynchronous gather of one overlaps the forwards that fill the
-    # other; every step's map is gathered inside the timed region (the tail is flushed before the clock stops).
-    G = max(1, -(-args.gather_pairs // B)) if grouped else 1
+    # the output disparities" of a batch).  The stage-4 maps of consecutive steps are written straight into the slots of a
+    # staging buffer (lws_forward's output pointer: no copy) and gathered together; how many pairs per rank one gather carries
+    # is a function of the world size (lwsnet_amd.dist.gather_policy: 8 pairs, 16 on eight ranks), chosen from the root-rank
+    # emulation of round 4 (profiles/r04/gather_root_emulation_d.txt).  Two staging buffers alternate, so
+    # the asynchronous gather of one overlaps the forwards that fill the other; every step's map is gathered inside the timed
+    # region (the tail is flushed before the clock stops).  NOTE (r04): in a world of ONE torch's NCCL gather is a tensor copy
+    # of the root's own shard -- no RCCL kernel runs -- so `collective.overhead_pct` of a one-rank run prices the staging, the
+    # stream hand-offs and that copy only.
+    G = ldist.gather_every(world, B, args.gather_pairs) if grouped else 1
     sg = ldist.StagedGather(B, H, W, G, dev, multi_stream=S > 1) if grouped else None
     counter = [0]
 
@@ -439,8 +440,7 @@ def main():
     # dominant kernel: stage-1 Conv3D c3 -> c3 (k_conv3d_mid16): 2*27*c3*c3 FLOP per voxel, voxels = B*D1*(H/8)*(W/8)
     c3 = margs.channels_3d * margs.growth_rate[0]
     h2_, w2_ = (H + 1) // 2, (W + 1) // 2                    # the stem gives ceil(H/2); the hourglass halves twice more
-    # pairs per launch: B, or B/2 when lws_forward splits a large batch over two streams (option split_batch: batches >= 8);
-    # read off the launch count of the breakdown pass rather than assumed
+    # pairs per launch: read off the launch count of the breakdown pass rather than assumed
     n_mid16 = kernels.get("conv3d_mid16", {}).get("launches_per_step", margs.layers_3d)
     pairs_per_launch = B * margs.layers_3d / max(n_mid16, 1)
     vox = pairs_per_launch * margs.maxdisplist[0] * (h2_ // 4) * (w2_ // 4)
@@ -465,8 +465,8 @@ def main():
         roof = {"bound": "mfma", "kernel": "k_conv3d_mid16x<3,4> (split-bf16, NOT the oracle chain)" if split else "k_conv3d_mid16<32,3,4>",
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "peak_note": "bf16 dense peak / 6 cross products" if split else
-                             "nominal: 64 FLOP/clk/SIMD at 2.4 GHz; the in-kernel clock of this kernel reads 2.10-2.14 GHz "
-                             "(profiles/r03/stamps_inkernel_clock.txt), i.e. 138-140 TF sustainable",
+                             "nominal: 64 FLOP/clk/SIMD at 2.4 GHz; the in-kernel clock of this kernel reads 2.13 GHz "
+                             "(profiles/r04/stamps_inkernel_clock.txt), i.e. ~140 TF sustainable",
                 "traffic": None, "flop_per_launch": flop_per_launch, "avg_launch_us": round(mid["avg_us"], 2),
                 "timed_launches": int(mid_n), "timed_every_nth_step": sample_every, "pairs_per_launch": pairs_per_launch}
     # the whole step against the same fp32-MFMA peak: algorithmic GF of a forward x pairs / step time.  This, not `frac`,
@@ -569,6 +569,21 @@ def main():
         cpu["noise_pair"] = {"max_abs_gpu_vs_fp64": dist64(npred, n64), "max_abs_literal_fp32_vs_fp64": dist64(n32, n64),
                              "max_abs_gpu_vs_literal_fp32": [round(float((npred[s] - n32[s]).abs().max()), 6) for s in range(4)]}
 
+        # ... and the pair BASELINE config 1 names (the reference's own KITTI frame, tests/golden/kitti_pair/: image data,
+        # cropped to 368x1232 and normalised as inference.py:94-103 does): the same account on real image statistics
+        kp = os.path.join(ROOT, "tests", "golden", "kitti_pair")
+        if os.path.isfile(os.path.join(kp, "left_test.png")) and tuple(margs.maxdisplist) == (24, 5, 5):
+            from lwsnet_amd import imageio
+            kl = imageio.to_input(imageio.crop_bottom_right(imageio.load_rgb(os.path.join(kp, "left_test.png"))))[None]
+            kr = imageio.to_input(imageio.crop_bottom_right(imageio.load_rgb(os.path.join(kp, "right_test.png"))))[None]
+            kpred = [p.cpu() for p in model(kl, kr)]
+            k32 = lws_oracle.forward(kl, kr, sd, margs.maxdisplist)
+            k64 = lws_oracle.forward(kl, kr, sd, margs.maxdisplist, dtype=torch.float64)
+            cpu["reference_pair_368x1232"] = {"max_abs_gpu_vs_fp64": dist64(kpred, k64), "max_abs_literal_fp32_vs_fp64": dist64(k32, k64),
+                                              "max_abs_gpu_vs_literal_fp32": [round(float((kpred[s] - k32[s]).abs().max()), 6) for s in range(4)],
+                                              "what": "reference/left_test.png + right_test.png (config 1's pair), seeded weights"}
+            _lib.check(lib.lws_reserve(model._h, B, H, W), "lws_reserve")
+
     pairs = world * B * args.steps
     dtype_name = "f32 (fp16-rounded features)" if args.feature_fp16 else "f32"
     if model.get_option("mid16_form") == 1 or model.get_option("conv64_form") == 1 or model.get_option("mid8_form") == 2:
@@ -584,7 +599,7 @@ def main():
                                 f"batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[{args.maxdisp0},5,5], all 4 stages"),
                    "pairs_per_gpu": B, "streams": S, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4 per {G * B} pairs per rank" if grouped else "single GPU",
                    "weights": "seeded synthetic (seed 7, calibrated BN)", "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), **({"options": args.opt} if args.opt else {})},
-        "roofline": _with_traffic(roof, B), "secondary": secondary, "cpu_baseline": cpu, "latency_ms": latency, "pipelined": pipelined,
+        "roofline": _with_traffic(roof, B, H, W, args.maxdisp0, args.feature_fp16), "secondary": secondary, "cpu_baseline": cpu, "latency_ms": latency, "pipelined": pipelined,
         "split_bf16": split_bf16,
         "hbm_kernels": hbm,
         "hot_path_kernel_ms_per_step": round(hot_ms, 4), "all_kernel_ms_per_step": round(all_ms, 4), "kernels": {k: {a: round(b, 2) for a, b in v.items()} for k, v in kernels.items()},

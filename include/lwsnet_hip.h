@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LWS_ABI_VERSION 5
+#define LWS_ABI_VERSION 6
 
 typedef enum {
     LWS_OK = 0,
@@ -165,6 +165,9 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "ref_pipe"       -1 (default: on from four chunks up), 0 / 1: consecutive refinement chunks alternate between the caller's
  *                    stream and the handle's side stream, one chunk's memory-bound blocks beside the other's 64 -> 32 convolution
  *                    (r03: 810 -> 833 pairs/s at 8 x 368x1232; two chunks only, 8 x 256x512: 2,958 -> 2,930, hence the default)
+ *   "mid8_balance"   1 (default) / 0: on grids of at most four small (3 x 4 x 32) tiles per CU, k_conv3d_mid8q takes the small
+ *                    tile and asks for 160 KB / k of LDS so that exactly k workgroups are resident per CU (one 256x512 pair at
+ *                    stage 3: 768 tiles = 3 per CU instead of 384 large tiles = 2 on half of the CUs); lws_pool workers run with 0
  *   "warp_form"      residual volumes of stages 2 and 3: 1 (default) = k_volume_l1_warp stages the right-feature window of a
  *                    64-pixel row segment (all channels, zero-filled outside the image) in LDS and computes the 2m - 1
  *                    hypotheses from it; 0 = every tap gathered from global memory (the form a tile falls back to when its
@@ -236,9 +239,16 @@ int lws_pool_reserve(lws_pool_handle p, int B, int H, int W);
 int lws_pool_submit(lws_pool_handle p, const float *left, const float *right, int B, int H, int W,
                     float *const pred_out[4], void *after_stream, int64_t *ticket);
 /* Blocks the calling thread until the job's outputs are complete in device memory; returns the job's status
- * (lws_last_error() then holds the worker's message).  A ticket may be waited for any number of times. */
+ * (lws_last_error() then holds the worker's message).  A ticket may be waited for any number of times while its slot is
+ * live (the 4 x workers most recent tickets); for an older, recycled ticket the job is complete by construction and the
+ * call returns the pool's STICKY status instead: the first failure of any job since the pool was created (or since
+ * lws_pool_clear_error), so a failed forward is never reported as success once its slot has been reused.  The same sticky
+ * status is returned by lws_pool_wait_all and refuses further lws_pool_submit calls until it is cleared.
+ * Options are FROZEN at lws_pool_create: the workers are clones taken then; a later lws_set_option on `model` does not reach
+ * them (create a new pool after changing options). */
 int lws_pool_wait(lws_pool_handle p, int64_t ticket);
 int lws_pool_wait_all(lws_pool_handle p);
+int lws_pool_clear_error(lws_pool_handle p);          /* ABI v6 */
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "lws_pool_submit": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp * 4, _vp, c_int64_p]),
     "lws_pool_wait": (_i, [_vp, ctypes.c_int64]),
     "lws_pool_wait_all": (_i, [_vp]),
+    "lws_pool_clear_error": (_i, [_vp]),
 }
 LWS_POOL_SIDE_STREAMS = 1
 LWS_KC_COUNT = 13
@@ -83,7 +84,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lws_abi_version() != 5:
+    if lib.lws_abi_version() != 6:
         raise RuntimeError("liblwsnet_hip.so ABI version mismatch; rebuild the extension")
     _lib = lib
     return lib

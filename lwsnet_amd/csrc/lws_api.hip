@@ -845,6 +845,8 @@ static void apply_options(lws_ctx *h)
         h->stage[i].mid8_form = h->opt.mid8_form;
         h->stage[i].dfast = h->opt.conv3d_order;
         h->stage[i].mid16_form = h->opt.mid16_form;
+        h->stage[i].mid8_balance = h->opt.mid8_balance;
+        h->stage[i].cu_count = h->cu_count;
     }
     h->net2d.r2_first.form = h->opt.conv64_form;
 }
@@ -863,6 +865,7 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"ref_chunk_mb", &h->opt.ref_chunk_mb},
                                                      {"ref_pipe", &h->opt.ref_pipe},
                                                      {"warp_form", &h->opt.warp_form},
+                                                     {"mid8_balance", &h->opt.mid8_balance},
                                                      {"device", &h->device},
                                                      {"mid8_form", &h->opt.mid8_form}};
     for (auto &e : tab)
@@ -1116,6 +1119,12 @@ int lws_finalize(lws_handle h)
         }
     }
     if (h->have_2d) bind_net2d(h, o2d);
+    {
+        int ncu = 0;
+        if (h->device >= 0 && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && ncu > 0)
+            h->cu_count = ncu;
+        (void)hipGetLastError();
+    }
     apply_options(h);
     h->finalized = true;
     return LWS_OK;

@@ -119,6 +119,8 @@ struct Stage3d {
     int c3 = 0;
     int mid8_form = 1;                 // 8 -> 8 layers: 0 = k_conv3d_mid8 (16x16x4, parity rows), 1 = k_conv3d_mid8q (4x4x1_16B)
     int mid16_form = 0;                // 32 -> 32 layers: 0 = k_conv3d_mid16 (f32 MFMA, the oracle's chain), 1 = k_conv3d_mid16x (split-bf16, not bit-exact)
+    int mid8_balance = 1;              // k_conv3d_mid8q on small grids: small tiles with the per-CU residency capped (even spread over the CUs)
+    int cu_count = 0;                  // compute units of the handle's device (0 = unknown: 256)
     int dfast = 1;                     // tile order of the stack's kernels: 0 = x, y, d; 1 = d fastest (tile_coords, lws_conv3d.hip)
     std::vector<Conv3dLayer> layers;   // layers_3d + 2
 };
@@ -180,6 +182,7 @@ struct lws_ctx {
         int conv64_form = 0;       // 1: refinement2[0] (64 -> 32, dilation 8) on split-bf16 MFMA (k_ref_conv64x): NOT bit-exact
         int conv3d_order = 1;      // tile order of the Conv3D stacks: 0 = x fastest, 1 = d fastest (halo planes shared inside an XCD's L2)
         int ref_pipe = -1;         // refinement chunks alternating over two streams: -1 = from four chunks up, 0 = never, 1 = from two chunks up
+        int mid8_balance = 1;      // k_conv3d_mid8q: small grids take small tiles with the residency capped so that every CU gets the same number
         int warp_form = 1;         // residual volumes: 1 = right-feature window of a 64-pixel row segment staged in LDS, 0 = every tap gathered from global memory
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
     } opt;
@@ -190,6 +193,7 @@ struct lws_ctx {
     std::vector<lws_prof_rec> prof;          // records of the current session
     std::vector<hipEvent_t> evt_pool;        // events available for reuse
     int device = 0;
+    int cu_count = 0;                        // compute units of `device` (lws_finalize)
     bool finalized = false;
     std::map<std::string, std::vector<float>> host;        // state dict as given
     std::map<std::string, std::vector<int64_t>> shapes;

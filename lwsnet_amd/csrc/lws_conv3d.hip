@@ -1541,18 +1541,28 @@ static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out,
     return LWS_OK;
 }
 
+// wg_per_cu > 0: the launch asks for 160 KB / wg_per_cu of LDS per workgroup instead of what the tile needs, so that at most
+// wg_per_cu workgroups are resident on a CU.  With a grid of at most wg_per_cu x (number of CUs) workgroups every CU then gets
+// the same number of tiles whatever order the dispatcher fills them in (left alone it packed up to four 32.6 KB workgroups on
+// some CUs and two on others: the launch lasted as long as its fullest CU).
+constexpr int kCuLdsBytes = 160 * 1024;
+
 template <int TD, int TY>
-static int mid8q_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w, hipStream_t st)
+static int mid8q_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w, hipStream_t st,
+                        int wg_per_cu = 0)
 {
     using Cfg = Mid8qCfg<TD, TY>;
     static std::atomic<uint64_t> attr_done{0};
-    if (Cfg::LDS_BYTES > 48 * 1024) {
-        const int rc_ = ensure_dyn_lds(attr_done, reinterpret_cast<const void *>(&k_conv3d_mid8q<TD, TY>), Cfg::LDS_BYTES);
+    int lds = Cfg::LDS_BYTES;
+    // (2 KB under the even share: with exactly 160 KB / 3 per workgroup only two were resident -- allocation granularity)
+    if (wg_per_cu > 1 && (kCuLdsBytes / wg_per_cu - 2048) / 256 * 256 > lds) lds = (kCuLdsBytes / wg_per_cu - 2048) / 256 * 256;
+    if (lds > 48 * 1024) {
+        const int rc_ = ensure_dyn_lds(attr_done, reinterpret_cast<const void *>(&k_conv3d_mid8q<TD, TY>), kCuLdsBytes);
         if (rc_) return rc_;
     }
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
-    hipLaunchKernelGGL((k_conv3d_mid8q<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w + MID8_PACK,
+    hipLaunchKernelGGL((k_conv3d_mid8q<TD, TY>), grid, block, lds, st, in, s.layers[layer].w + MID8_PACK,
                        s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, /*wt=*/0,
                        2 * tiles_d + (s.dfast ? 1 : 0));
     LWS_LAUNCH_CHECK();
@@ -1592,7 +1602,10 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
             // fill the chip stay on the exact kernel (dispatch-bound either way).  Other shapes of the same kernel, 8 x 9x128x256 /
             // 1 x 9x128x256 / 8 x 9x184x616: 6 waves x 2 rows (142 VGPRs, 3 waves per SIMD) 96.5 / 14.7 / 381 us, 3 x 8 x 32 tiles
             // with 12 waves 77.2 / 14.7 / 306, this one (4 waves x 3 rows, 188 VGPRs) 70.7 / 12.4 / 272.
-            if (s.mid8_form == 2 && (long)cdiv(w, 32) * cdiv(h, 4) * cdiv(D, 3) * B >= 256)
+            // (the choice depends on the per-SAMPLE geometry only, never on B: in this mode -- the only one whose two
+            // candidate kernels differ in bits -- a pair must get the same bits at every batch size, so that the sharded /
+            // pooled / batched results stay equal to each other: ADVICE r3)
+            if (s.mid8_form == 2 && (long)cdiv(w, 32) * cdiv(h, 4) * cdiv(D, 3) >= 256)
                 return mid8x_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
             if (s.mid8_form >= 1) {
                 // Tile: 3 x 8 x 32 voxels (12 waves, 54 KB of LDS, halo 2.21x) once there are enough of them to fill the chip,
@@ -1602,9 +1615,18 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
                 // 0.64 of the peak), 8 x 9x64x128 30.4 -> 24.1, 2 x 9x128x256 29.3 -> 23.2, 2 x 9x64x128 12.4 -> 10.7,
                 // 8 x 9x184x616 332 -> 303, 8 x 9x92x308 85.9 -> 78.1; 1 x 9x128x256 (384 large tiles) 16.3 -> 16.3;
                 // 1 x 9x64x128 (96 large tiles) 7.8 -> 9.4: hence the threshold.
+                // Round 4: a launch lasts as long as its fullest CU (the MFMA issue rate of the 4x4x1 form bounds a CU: 5,184
+                // instructions per large tile / 4 SIMDs x 10 cycles).  One 256x512 pair at stage 3 is 384 large tiles on 256 CUs
+                // -- two on half of them, 1,536 voxels -- or 768 small ones, three per CU = 1,152 voxels IF they are spread evenly:
+                // small tiles with the residency capped at ks per CU (mid8q_launch) whenever that is the shorter schedule and
+                // ks <= 4; larger grids balance statistically and take the large tile.
                 const long big_tiles = (long)cdiv(w, 32) * cdiv(h, 8) * cdiv(D, 3) * B;
-                if (big_tiles >= 192) return mid8q_launch<3, 8>(s, layer, act_in, act_out, B, D, h, w, st);
-                return mid8q_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+                const long small_tiles = (long)cdiv(w, 32) * cdiv(h, 4) * cdiv(D, 3) * B;
+                const long ncu = s.cu_count > 0 ? s.cu_count : 256;
+                const long ks = (small_tiles + ncu - 1) / ncu, kl = (big_tiles + ncu - 1) / ncu;
+                const bool small_wins = s.mid8_balance != 0 && ks <= 4 && ks * 384 < kl * 768;
+                if (big_tiles >= 192 && !small_wins) return mid8q_launch<3, 8>(s, layer, act_in, act_out, B, D, h, w, st);
+                return mid8q_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st, (s.mid8_balance != 0 && ks <= 4) ? (int)ks : 0);
             }
             return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
         }

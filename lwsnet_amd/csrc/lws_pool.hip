@@ -46,6 +46,12 @@ struct lws_pool {
     std::vector<Job> slots;       // ring: ticket t lives in slot t % slots.size()
     int64_t next_ticket = 0;
     bool stop = false;
+    // sticky first failure of any job: a slot is recycled 4 x workers submits later and its rc / message with it,
+    // so a failed forward outside that window would otherwise read as success.  Reported by wait on a recycled ticket,
+    // by wait_all and by the next submit; cleared by lws_pool_clear_error.
+    int sticky_rc = LWS_OK;
+    int64_t sticky_ticket = -1;
+    std::string sticky_err;
 };
 
 static void worker_main(lws_pool *p, int wi)
@@ -83,6 +89,11 @@ static void worker_main(lws_pool *p, int wi)
             j.rc = rc;
             j.err = err;
             j.state = JOB_ISSUED;
+            if (rc != LWS_OK && p->sticky_rc == LWS_OK) {
+                p->sticky_rc = rc;
+                p->sticky_ticket = j.ticket;
+                p->sticky_err = err;
+            }
         }
         p->cv_done.notify_all();
     }
@@ -172,6 +183,10 @@ int lws_pool_create(lws_handle src, int workers, int flags, lws_pool_handle *out
         p->workers.push_back(h);
         // one stream = one hardware queue per worker unless the caller asks for the per-handle side streams too
         h->opt.side_streams = (flags & LWS_POOL_SIDE_STREAMS) ? 1 : 0;
+        // several forwards share the CUs: no residency cap on k_conv3d_mid8q (a capped workgroup holds a third of a CU's LDS
+        // idle, which the kernels of the other workers' forwards could use)
+        h->opt.mid8_balance = 0;
+        for (int s_ = 0; s_ < 3; ++s_) h->stage[s_].mid8_balance = 0;
         hipStream_t st = nullptr;
         if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
             set_error("lws_pool_create: hipStreamCreate failed");
@@ -212,6 +227,10 @@ int lws_pool_submit(lws_pool_handle p, const float *left, const float *right, in
     if (p->stop) {
         set_error("lws_pool_submit: the pool is shutting down");
         return LWS_ERR_STATE;
+    }
+    if (p->sticky_rc != LWS_OK) {
+        set_error("lws_pool_submit: an earlier job (ticket %lld) failed: %s", (long long)p->sticky_ticket, p->sticky_err.c_str());
+        return p->sticky_rc;
     }
     const int64_t t = p->next_ticket++;          // the ticket (and with it the slot) is this call's from here on
     const int slot = (int)(t % (int64_t)p->slots.size());
@@ -263,9 +282,19 @@ int lws_pool_wait(lws_pool_handle p, int64_t ticket)
     LWS_CHECK_ARG(ticket >= 0 && ticket < p->next_ticket, "lws_pool_wait: ticket %lld was never issued", (long long)ticket);
     const int slot = (int)(ticket % (int64_t)p->slots.size());
     Job &j = p->slots[slot];
-    if (j.ticket != ticket) return LWS_OK;      // the slot has been recycled: that required the job to be complete
+    // the slot has been recycled: that required the job to be complete; its own status is gone, the pool's first failure is not
+    auto recycled = [&]() -> int {
+        // (tickets older than the FIRST failure ran to completion; anything from it on may have failed unrecorded)
+        if (p->sticky_rc != LWS_OK && ticket >= p->sticky_ticket) {
+            set_error("lws_pool_wait: ticket %lld has been recycled; the pool's first failed job was ticket %lld: %s",
+                      (long long)ticket, (long long)p->sticky_ticket, p->sticky_err.c_str());
+            return p->sticky_rc;
+        }
+        return LWS_OK;
+    };
+    if (j.ticket != ticket) return recycled();
     p->cv_done.wait(lk, [&] { return j.ticket != ticket || j.state == JOB_ISSUED || j.state == JOB_FREE; });
-    if (j.ticket != ticket || j.state == JOB_FREE) return LWS_OK;
+    if (j.ticket != ticket || j.state == JOB_FREE) return recycled();
     const int rc = j.rc;
     const std::string err = j.err;
     hipEvent_t done = j.done;
@@ -297,8 +326,25 @@ int lws_pool_wait_all(lws_pool_handle p)
             first_err = lws_last_error();
         }
     }
+    if (first_rc == LWS_OK) {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (p->sticky_rc != LWS_OK) {            // a failure older than the 4 x workers tickets scanned above
+            first_rc = p->sticky_rc;
+            first_err = "ticket " + std::to_string(p->sticky_ticket) + ": " + p->sticky_err;
+        }
+    }
     if (first_rc != LWS_OK) set_error("%s", first_err.c_str());
     return first_rc;
+}
+
+int lws_pool_clear_error(lws_pool_handle p)
+{
+    LWS_CHECK_ARG(p, "lws_pool_clear_error: null pool");
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->sticky_rc = LWS_OK;
+    p->sticky_ticket = -1;
+    p->sticky_err.clear();
+    return LWS_OK;
 }
 
 int lws_pool_destroy(lws_pool_handle p)

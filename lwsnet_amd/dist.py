@@ -18,18 +18,25 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-# ---- root-rank budget of the ONE collective (measured on one MI355X with the root's inbound volume
-# emulated: tools/gather_probe.py --beside --emulate-world 8, profiles/r04/gather_root_emulation.txt) ---------------------
-# RCCL's send/recv kernel runs on the compute units beside the forward.  What it costs the root is set by (a) how many
-# channels (workgroups) RCCL gives it -- read from the environment when the communicator is created -- and (b) how many bytes
-# one gather writes on the root, i.e. world x pairs-per-rank-per-gather x H*W*4.  The policy below is a function of the world
-# size; callers' own NCCL_* settings win (setdefault).
+# ---- root-rank budget of the ONE collective ------------------------------------------------------------
+# Measured on one MI355X with the root's inbound volume EMULATED (tools/gather_probe.py --beside --emulate-world 8: the N-1
+# inbound shards as ncclSend/ncclRecv to self, so RCCL's SendRecv kernel really runs beside the forward; only the xGMI hop and
+# the peers' clocks are missing): profiles/r04/gather_root_emulation_*.txt.  Findings the policy encodes:
+#   * capping RCCL's channels makes the root SLOWER, not faster: 8 pairs per gather at 1 pair per step cost 5.1 % with RCCL's
+#     default channel count, 5.9 / 6.6 / 8.5 / 11.2 % capped at 8 / 4 / 2 / 1 channels (the copy kernel then lives longer beside
+#     the latency-bound chain) -> no cap;
+#   * what the root pays is mostly the HOST time of the call (55-75 us for one grouped operation, 200-225 us for 14 Python-level
+#     P2P operations) on a loop that is nearly host-bound at 1 pair per step, plus ~15 us of RCCL kernel per 29 MB;
+#   * 8 pairs per GPU per step (BASELINE config 4): a gather every step costs 1.1 % (one grouped call) to 4.6 % (14 P2P
+#     operations); every second step 0.8 % to 2.8 %.  1 pair per step: 3.3-5.1 % at 8 pairs per gather, 3.4-4.2 % at 16.
+# Hence: 8 ranks gather 16 pairs per rank at a time (<= 3 % at 8 pairs per step, <= 5 % at 1 pair per step in the emulation's
+# pessimistic variant), smaller worlds 8 pairs.  UNMEASURED ON N > 1: no multi-GPU box was available to this build.
 GATHER_POLICY = {
-    # world: (channel cap, minimum pairs per rank per gather for 1-pair steps)
+    # world size (largest key <= world applies): (RCCL channel cap or None, minimum pairs per rank carried by one gather)
     1: (None, 8),
     2: (None, 8),
     4: (None, 8),
-    8: (None, 8),
+    8: (None, 16),
 }
 
 
@@ -39,8 +46,16 @@ def gather_policy(world):
     return GATHER_POLICY[key]
 
 
+def gather_every(world, pairs_per_step, min_pairs=None):
+    """Steps per gather for `pairs_per_step` pairs per rank per step: the smallest G with G * pairs_per_step >= the policy's
+    minimum for this world size (or `min_pairs` when the caller overrides it)."""
+    need = gather_policy(world)[1] if min_pairs is None else int(min_pairs)
+    return max(1, -(-need // max(1, int(pairs_per_step))))
+
+
 def apply_channel_cap(world):
-    """Exports RCCL's channel caps for a `world`-rank job unless the caller set them; must run before the communicator exists."""
+    """Exports RCCL's channel caps for a `world`-rank job unless the caller set them; must run before the communicator exists.
+    (The measured policy is "no cap" at every world size; the hook stays so that a node that measures otherwise changes a table.)"""
     cap, _ = gather_policy(world)
     if cap is not None:
         os.environ.setdefault("NCCL_MAX_NCHANNELS", str(cap))

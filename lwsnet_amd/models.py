@@ -231,6 +231,7 @@ class ForwardPool:
         self._lib = _lib.load()
         self._p = ctypes.c_void_p()
         self._shape = None
+        self._live = {}                         # ticket -> (left, right, outs) of jobs that may still be running
         with torch.cuda.device(model.device):
             _lib.check(self._lib.lws_pool_create(model._h, workers, _lib.LWS_POOL_SIDE_STREAMS if side_streams else 0,
                                                  ctypes.byref(self._p)), "lws_pool_create")
@@ -249,7 +250,7 @@ class ForwardPool:
             raise ValueError(f"left/right shapes differ: {tuple(left.shape)} vs {tuple(right.shape)}")
         B, _, H, W = left.shape
         check_size(H, W, m.maxdisplist[0])
-        outs = out if out is not None else [torch.empty((B, 1, H, W), device=left.device, dtype=torch.float32) for _ in range(4)]
+        outs = ops.stage_outputs(out, B, H, W, left.device)          # validated: raw pointers go to a worker thread
         ticket = ctypes.c_int64(-1)
         with torch.cuda.device(m.device):
             if self._shape is None or B > self._shape[0] or (H, W) != tuple(self._shape[1:]):
@@ -258,18 +259,32 @@ class ForwardPool:
             after = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             _lib.check(self._lib.lws_pool_submit(self._p, ctypes.c_void_p(left.data_ptr()), ctypes.c_void_p(right.data_ptr()),
                                                  B, H, W, ptrs, after, ctypes.byref(ticket)), "lws_pool_submit")
+        # the pool itself keeps the inputs and outputs alive until the ticket has completed: a job object dropped without
+        # result() must not hand its tensors back to the caching allocator while a worker's stream still uses them
+        self._live[ticket.value] = (left, right, outs)
         return _PoolJob(self, ticket.value, (left, right), outs)
 
     def _wait(self, ticket):
-        _lib.check(self._lib.lws_pool_wait(self._p, ctypes.c_int64(ticket)), "lws_pool_wait")
+        try:
+            _lib.check(self._lib.lws_pool_wait(self._p, ctypes.c_int64(ticket)), "lws_pool_wait")
+        finally:
+            self._live.pop(ticket, None)
 
     def wait_all(self):
-        _lib.check(self._lib.lws_pool_wait_all(self._p), "lws_pool_wait_all")
+        try:
+            _lib.check(self._lib.lws_pool_wait_all(self._p), "lws_pool_wait_all")
+        finally:
+            self._live.clear()
+
+    def clear_error(self):
+        """Clears the pool's sticky first-failure status (lws_pool_clear_error) so that submits are accepted again."""
+        _lib.check(self._lib.lws_pool_clear_error(self._p), "lws_pool_clear_error")
 
     def close(self):
         if self._p:
-            self._lib.lws_pool_destroy(self._p)
+            self._lib.lws_pool_destroy(self._p)          # runs what is queued, joins the workers, synchronises their streams
             self._p = ctypes.c_void_p()
+        self._live.clear()
 
     def __enter__(self):
         return self

@@ -151,21 +151,31 @@ def refine(handle, left, pred3):
     return out
 
 
+def stage_outputs(out, B, H, W, device):
+    """The four [B,1,H,W] destinations of a forward: `out` is None or a list of four entries, each None (allocated here) or
+    a contiguous float32 tensor of exactly that shape on `device` -- a raw pointer is handed to the library, so a strided or
+    wrong-sized tensor would be an out-of-bounds device write (shared by ops.forward and ForwardPool.submit)."""
+    if out is not None and (not isinstance(out, (list, tuple)) or len(out) != 4):
+        raise ValueError("out must be a list of four tensors (or None entries), one per stage")
+    preds = []
+    for s in range(4):
+        t = out[s] if out is not None else None
+        if t is None:
+            t = torch.empty((B, 1, H, W), device=device, dtype=torch.float32)
+        elif not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == torch.device(device) and t.dtype == torch.float32
+                  and t.is_contiguous() and tuple(t.shape) == (B, 1, H, W)):
+            raise ValueError(f"out[{s}] must be a contiguous float32 tensor of shape {(B, 1, H, W)} on {device}")
+        preds.append(t)
+    return preds
+
+
 def forward(handle, left, right, out=None):
     """LWSNet.forward (models/models.py:106-164): list of 4 x [B,1,H,W].  `out` (optional): a list of four destinations;
     entries that are None are allocated here, the others must be contiguous float32 [B,1,H,W] device tensors (a slot of
     a staging buffer, say) and are written in place."""
     l, r = _dev(left, "left"), _dev(right, "right")
     B, _, H, W = l.shape
-    preds = []
-    for s in range(4):
-        t = out[s] if out is not None else None
-        if t is None:
-            t = torch.empty((B, 1, H, W), device=l.device, dtype=torch.float32)
-        elif not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
-                  and tuple(t.shape) == (B, 1, H, W)):
-            raise ValueError(f"out[{s}] must be a contiguous float32 device tensor of shape {(B, 1, H, W)}")
-        preds.append(t)
+    preds = stage_outputs(out, B, H, W, l.device)
     arr = ctypes.c_void_p * 4
     lib = _lib.load()
     with torch.cuda.device(l.device):

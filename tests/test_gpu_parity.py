@@ -5,7 +5,9 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+import os
+
+from conftest import ROOT, golden
 from lwsnet_amd.synth import make_batch
 from lwsnet_amd.weights import default_args, make_state_dict
 
@@ -251,7 +253,7 @@ def test_refine_chunks_over_two_streams(dev, model):
         model.set_option("ref_pipe", -1)
 
 
-@pytest.mark.parametrize("B,H,W", [(1, 64, 256), (2, 40, 72), (1, 136, 152), (1, 63, 255)])
+@pytest.mark.parametrize("B,H,W", [(1, 64, 256), (2, 40, 72), (1, 136, 152), (1, 63, 255), (3, 33, 47)])
 @pytest.mark.parametrize("chunk_mb", [72, 1])
 def test_refine_bitexact(dev, model, B, H, W, chunk_mb):
     """chunk_mb = 1: the refinement runs one pair per chunk (option ref_chunk_mb; pairs are independent, so the same bits)."""
@@ -354,7 +356,7 @@ OPTION_PLANS = [{"left_at": 0}, {"left_at": 2}, {"split_heads": 1}, {"split_head
                 {"fuse_first": 0}, {"defer_upsample": 0}, {"mid8_form": 1}, {"mid8_form": 0},
                 {"conv3d_order": 1}, {"conv3d_order": 0}, {"ref_chunk_mb": 0}, {"ref_chunk_mb": 1},
                 {"side_streams": 0}, {"side_streams": 0, "left_at": 0}, {"left_at": 2, "split_heads": 1},
-                {"warp_form": 0}, {"warp_form": 0, "defer_upsample": 0},
+                {"warp_form": 0}, {"warp_form": 0, "defer_upsample": 0}, {"mid8_balance": 0},
                 {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0, "mid8_form": 1}]
 
 
@@ -481,16 +483,41 @@ def test_pool_reports_a_workers_error_at_wait(dev, model, hip_lib):
             assert rc == 0, hip_lib.lws_last_error()
             return t.value
         t0 = submit(lt, rt, 64, 256, outs[0])
-        t1 = submit(bad_l, bad_l, 30, 256, outs[1])
         t2 = submit(lt, rt, 64, 256, outs[2])
+        t1 = submit(bad_l, bad_l, 30, 256, outs[1])                      # (last: a failure refuses later submits, below)
         assert hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(t1)) == _lib.LWS_ERR_INVALID
         assert b"30" in hip_lib.lws_last_error()
         assert hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(t0)) == 0 and hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(t2)) == 0
         assert hip_lib.lws_pool_wait_all(pool._p) == _lib.LWS_ERR_INVALID
-        assert hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(t2 + 1)) == _lib.LWS_ERR_INVALID          # never issued
+        assert hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(t1 + 1)) == _lib.LWS_ERR_INVALID          # never issued
         torch.cuda.synchronize()
         for o in (outs[0], outs[2]):
             assert all(torch.equal(a, b) for a, b in zip(o, want))
+        # the failure is STICKY (ABI v6): further submits are refused with it until it is cleared ...
+        t = ctypes.c_int64(-1)
+        ptrs = (ctypes.c_void_p * 4)(*[x.data_ptr() for x in outs[0]])
+        assert hip_lib.lws_pool_submit(pool._p, ctypes.c_void_p(lt.data_ptr()), ctypes.c_void_p(rt.data_ptr()), 1, 64, 256, ptrs,
+                                       stream, ctypes.byref(t)) == _lib.LWS_ERR_INVALID
+        assert b"earlier job" in hip_lib.lws_last_error()
+        with pytest.raises(ValueError, match="earlier job"):
+            pool.submit(lt, rt)
+        # ... and a ticket whose slot has been recycled (4 x workers = 8 submits later) still reports it, not success
+        pool.clear_error()
+        for _ in range(9):
+            pool.submit(lt, rt).result()
+        assert hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(t0)) == 0                                 # recycled, no failure on record
+        tb = submit(bad_l, bad_l, 30, 256, outs[1])
+        assert hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(tb)) == _lib.LWS_ERR_INVALID
+        assert hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(t0)) == 0                                 # older than the failure's window
+        assert hip_lib.lws_pool_wait_all(pool._p) == _lib.LWS_ERR_INVALID
+        pool.clear_error()
+        assert hip_lib.lws_pool_wait_all(pool._p) == _lib.LWS_ERR_INVALID and b"30" in hip_lib.lws_last_error()   # tb's slot is still live
+        # ForwardPool.submit validates the destinations before a raw pointer reaches a worker thread
+        big = torch.empty((2, 1, 64, 256), device=dev)
+        for bad in ([big[:1]] * 3, [torch.empty((1, 1, 64, 255), device=dev)] * 4, [big[:, :, ::2][:1]] * 4,
+                    [torch.empty((1, 1, 64, 256))] * 4):
+            with pytest.raises(ValueError):
+                pool.submit(lt, rt, out=bad)
 
 
 def test_clone_shares_parameters(dev, model, hip_lib):
@@ -826,6 +853,35 @@ def test_inference_cli_writes_four_stage_maps(dev, hip_lib, tmp_path):
     assert np.array_equal(np.asarray(Image.open(written[3])), want)
     with pytest.raises(SystemExit):                    # inference.py:41-43: missing checkpoint
         inference.main(["--left_img", str(tmp_path / "left_test.png"), "--model", str(tmp_path / "missing.pdparams")])
+
+
+def test_config1_reference_pair_through_the_cli(dev, hip_lib, tmp_path):
+    """BASELINE config 1 on the pair it names: `inference.py --left_img reference/left_test.png` (/root/reference/
+    inference.py:65-70,94-122) -- the reference's own KITTI frame (tests/golden/kitti_pair/, image data), cropped bottom-right
+    to 368x1232, normalised, run through the HIP path with the seeded weights; four colour-mapped 368x1232 PNGs appear beside
+    the left image, and the four stage maps equal the C oracle on the same cropped pair bit for bit (real image statistics
+    instead of the synthetic pairs every other parity test uses)."""
+    import shutil
+    from PIL import Image
+    from lwsnet_amd import imageio, inference
+    from lwsnet_amd.models import LWSNet
+    from oracle import c_oracle as C
+    src = os.path.join(ROOT, "tests", "golden", "kitti_pair")
+    for n in ("left_test.png", "right_test.png"):
+        shutil.copy(os.path.join(src, n), tmp_path / n)
+    written = inference.main(["--left_img", str(tmp_path / "left_test.png"), "--synthetic_weights"])
+    assert [os.path.basename(p) for p in written] == ["1.png", "2.png", "3.png", "4.png"]
+    left = imageio.to_input(imageio.crop_bottom_right(imageio.load_rgb(str(tmp_path / "left_test.png"))))[None]
+    right = imageio.to_input(imageio.crop_bottom_right(imageio.load_rgb(str(tmp_path / "right_test.png"))))[None]
+    assert left.shape == (1, 3, 368, 1232)
+    sd = make_state_dict(7)
+    m = LWSNet(default_args(), device=dev).set_state_dict(sd).eval()
+    pred = m(left, right)
+    want = C.forward(left, right, sd)
+    for s in range(4):
+        assert_bits(pred[s], want[s], f"reference pair, stage {s + 1}")
+        png = np.asarray(Image.open(written[s]))
+        assert png.shape == (368, 1232, 3) and np.array_equal(png, imageio.disparity_to_color(want[s][0, 0]))
 
 
 def test_dropin_inference_expression_sequence(dev, model):

@@ -8,7 +8,8 @@ CAUTION: a stamped build is a different kernel.  The inline asm can change its r
 the shipped build, 300 with stamps -- one workgroup per CU instead of three): compare `.amdhsa_next_free_vgpr` of the two builds
 (hipcc --save-temps) before reading residency or phase times off a stamped run."""
 import ctypes, os, subprocess, sys
-sys.path.insert(0, '/root/repo')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 KERNELS = {  # name: (stamp id, translation unit, driver, arg)
     "mid16": (1, "conv3d", "stack", 0), "mid8_2": (2, "conv3d", "stack", 1), "mid8_3": (2, "conv3d", "stack", 2),
     "last1": (3, "conv3d", "stack", 0), "last3": (3, "conv3d", "stack", 2),
@@ -26,7 +27,7 @@ what = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 kid, TU, driver, arg = KERNELS[what]
 env = dict(os.environ, LWS_EXTRA_FLAGS=f"-DLWS_STAMPS={kid}")
-subprocess.check_call([sys.executable, "-m", "lwsnet_amd.build", "--force"], env=env, stdout=subprocess.DEVNULL, cwd="/root/repo")
+subprocess.check_call([sys.executable, "-m", "lwsnet_amd.build", "--force"], env=env, stdout=subprocess.DEVNULL, cwd=ROOT)
 import numpy as np, torch
 from lwsnet_amd import _lib, ops
 from lwsnet_amd.models import LWSNet
