@@ -142,7 +142,7 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *                    broadcast (k_conv3d_mid8q: 4 couts x 64 voxels per instruction, no padding), 0 = v_mfma_f32_16x16x4_f32
  *                    with rows = (x parity, cout) (k_conv3d_mid8: 25 % of every instruction is structural zero padding;
  *                    measured r03 10-25 % slower); k_conv3d_mid8q picks 3 x 8 x 32 or 3 x 4 x 32 voxel tiles by grid size;
- *                    2 = k_conv3d_mid8x, split-bf16 MFMA (NOT bit-exact, see "split_bf16"; grids under 256 tiles stay on
+ *                    2 = k_conv3d_mid8x, split-bf16 MFMA (NOT bit-exact, see "split_bf16"; samples under 256 tiles stay on
  *                    k_conv3d_mid8q)
  *   "mid16_form"     0 (default) = the 32 -> 32 Conv3D layers on the f32-input MFMA, the oracle's fma chain bit for bit;
  *                    1 = k_conv3d_mid16x: split-bf16 MFMA (each float32 operand as three bf16 values, six exact cross

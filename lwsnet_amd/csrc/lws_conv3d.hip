@@ -1625,8 +1625,12 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
                 const long ncu = s.cu_count > 0 ? s.cu_count : 256;
                 const long ks = (small_tiles + ncu - 1) / ncu, kl = (big_tiles + ncu - 1) / ncu;
                 const bool small_wins = s.mid8_balance != 0 && ks <= 4 && ks * 384 < kl * 768;
+                const int cap = (s.mid8_balance != 0 && ks <= 4) ? (int)ks : 0;
+                // (Round 4, built, bit-exact, measured, removed: the same tiles on packed float32 VALU -- v_pk_fma_f32 with the
+                // weights as SGPR pairs, priced at 119-122 TF by tools/micro/pkfma_conv.hip -- ran at 76 TF in place against this
+                // kernel's 100 at 8 x 9x128x256, 43 vs 61 at B = 1: profiles/r04/experiments/sbench_mid8v_packed_valu_form.txt.)
                 if (big_tiles >= 192 && !small_wins) return mid8q_launch<3, 8>(s, layer, act_in, act_out, B, D, h, w, st);
-                return mid8q_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st, (s.mid8_balance != 0 && ks <= 4) ? (int)ks : 0);
+                return mid8q_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st, cap);
             }
             return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
         }
