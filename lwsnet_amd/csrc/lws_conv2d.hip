@@ -14,8 +14,6 @@
 // outputs plane by plane, coalesced along W).  The refinement works on channels-last [B,H,W,32] maps: one pixel
 // = one 128-byte line, so dilated taps (dilation 2..16) and the strided "phase grid" tiles below always move whole
 // cache lines.
-#include <stdlib.h>
-
 #include "lws_common.h"
 #include "lws_device_math.h"
 
