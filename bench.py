@@ -266,15 +266,14 @@ def main():
     spun_s = time.perf_counter() - t_spin
     for _ in range(args.warmup):
         step()
-    # inside the timed region only the dominant kernel class is bracketed by hipEvents (8 events per step);
-    # the per-class breakdown comes from a separate, untimed pass below
-    # and only on every n-th step (its begin/end events keep the next kernel from being queued behind it: ~3 us
-    # of extra gap per timed launch at batch 1) -- at least ~48 timed launches with the default 50 steps.
+    # inside the timed region only the dominant kernel class is bracketed by hipEvents (8 events per sampled step), and only
+    # on every n-th step; the per-class breakdown comes from a separate, untimed pass below.  A kernel bracketed by its own
+    # events keeps its successor from being queued behind it: ~3 us per timed launch at batch 1 unprofiled, 8 us under a
+    # kernel trace (profiles/r04/timeline_b1_trace_only.txt shows such a forward), so timing EVERY step of a short run taxed
+    # the headline by 3-4 %.  Every 8th step (round 4; every 4th before): the driver's --steps 20 gives 3 sampled
+    # steps = 12 timed launches, the default 50 steps 7 = 28; the durations spread by +-1 %.
     KC_MID16, KC_CONV64 = 3, 11          # LWS_KC_CONV3D_MID16, LWS_KC_REF_CONV64 (include/lwsnet_hip.h)
-    # every 4th step at least: a kernel bracketed by its own events keeps its successor from being queued behind it
-    # (~3 us each at batch 1), so timing EVERY step of a short run (the driver's --steps 20) taxed the headline by 3-4 %
-    # (VERDICT r2).  20 steps -> 5 sampled steps -> 20 timed launches.
-    sample_every = max(4, (args.steps // S) // 12)
+    sample_every = max(8, (args.steps // S) // 12)
     for m in models:
         _lib.check(lib.lws_profile_enable(m._h, 1 << KC_MID16), "lws_profile_enable")
         _lib.check(lib.lws_profile_sample(m._h, sample_every), "lws_profile_sample")
