@@ -50,11 +50,13 @@ def test_bench_under_torchrun_world1(hip_lib):
 @pytest.mark.parametrize("batch,limit", [(8, 3.0), (1, 7.0)])
 def test_gather_cost_per_step(hip_lib, batch, limit):
     """SURVEY.md section 8e budgets the ONE collective of the path at <= 3 % of a step for 8 pairs per GPU per step
-    (BASELINE config 4): asserted here.  bench.py under torchrun times the same K steps with and without the asynchronous
-    RCCL gather (`collective.overhead_pct`); on one GPU the send/recv kernels and their launch cost are all there, only
-    the xGMI hop is missing (<= 27 us per 4 MB map).  Measured r03: 0.3-0.5 % at batch 8.  At ONE pair per step (0.5 ms
-    steps, 8 pairs per staged gather) RCCL's kernel beside the running forward costs 2.3-4.4 % (5.9-7.8 % with a gather per
-    step): bounded at 7 % here, recorded in DESIGN.md section 5."""
+    (BASELINE config 4): asserted here for what one GPU can show.  bench.py under torchrun times the same K steps with and
+    without the staged asynchronous gather (`collective.overhead_pct`).  NOTE (round 4): in a world of ONE torch's NCCL gather
+    copies the root's own shard with a tensor copy and posts ncclRecv for other ranks only, so NO RCCL kernel runs here -- this
+    prices the staging, the stream hand-offs and that copy (measured 0.03-0.5 % at batch 8, 2.3-4.4 % at one pair per step).
+    The root rank's budget with RCCL's SendRecv kernel really moving the inbound shards is measured by
+    tools/gather_probe.py --beside --emulate-world 8 (profiles/r04/gather_root_emulation_d.txt); N > 1 is
+    unmeasured."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "100" if batch == 1 else "40", "--warmup", "10",
            "--batch", str(batch), "--no-cpu-baseline"]
