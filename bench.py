@@ -121,6 +121,7 @@ def dry_run(args, rank, world):
     # alternation of the two staging buffers and the tail flush all occur; step k "sees" pairs shifted by k so that a
     # stale or misplaced slot cannot pass the check below
     sg = ldist.StagedGather(B, 16, 32, 2, torch.device("cpu"))
+    sg.warm()                                            # (as the measured path does: first-collective set-up outside the clock)
     nsteps = args.warmup + args.steps
     if grouped:
         dist.barrier()
@@ -264,8 +265,13 @@ def main():
         settled = prev is not None and abs(dt - prev) <= 0.01 * prev
         prev = dt
     spun_s = time.perf_counter() - t_spin
+    if grouped:
+        sg.warm()                        # the communicator's one-time set-up must not land in the timed region
     for _ in range(args.warmup):
         step()
+    if grouped:
+        sg.flush()                       # ... nor a half-filled buffer of warm-up steps
+        sg.buf, sg.fill = 0, 0
     # inside the timed region only the dominant kernel class is bracketed by hipEvents (8 events per sampled step), and only
     # on every n-th step; the per-class breakdown comes from a separate, untimed pass below.  A kernel bracketed by its own
     # events keeps its successor from being queued behind it: ~3 us per timed launch at batch 1 unprofiled, 8 us under a

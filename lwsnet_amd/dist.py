@@ -130,10 +130,10 @@ class StagedGather:
     fill the other.  `flush()` gathers a partly filled buffer (the tail) and waits for everything in flight.
     Rank `dst` reads the gathered maps of rank r, gather g (0 = most recent completed) from `gathered(r)`.
 
-    With `multi_stream=True` steps may run on DIFFERENT streams (bench.py --streams N): `commit()` records an event on the stream that produced the
-    slot and the gather is ordered behind every slot's event; `slot()` makes the current stream wait until the previous
-    gather out of the buffer it hands out has completed (the gather used to be ordered behind the last
-    committing stream only)."""
+    With `multi_stream=True` steps may run on DIFFERENT streams (bench.py --streams N): `commit()` notes the stream that
+    produced the slot and the gather is ordered behind every such stream (one event per stream per gather); `slot()` makes a
+    stream wait, once, until the previous gather out of the buffer it hands out has completed (the gather used
+    to be ordered behind the last committing stream only)."""
 
     def __init__(self, B, H, W, group, device, dtype=torch.float32, dst=0, multi_stream=False):
         self.B, self.group, self.dst = int(B), max(1, int(group)), dst
@@ -147,24 +147,33 @@ class StagedGather:
         self.buf, self.fill, self.count = 0, 0, 0
         self.last = None                      # (buffer, slots filled) of the most recent gather
         self.on_gpu = bool(multi_stream) and torch.device(device).type == "cuda"   # events only when steps use several streams
-        self.slot_events = [[], []]           # per staging buffer: (stream, event) of every committed slot
-        self.free_event = [None, None]        # per staging buffer: recorded once its previous gather has completed
+        self.slot_streams = [set(), set()]    # per staging buffer: the streams that committed slots into it
+        self.free_event = [None, None]        # per staging buffer: (event recorded once its previous gather completed, streams that waited)
 
     def slot(self):
         """Destination [B,1,H,W] for this step's stage-4 map (valid on the CURRENT stream)."""
-        ev = self.free_event[self.buf]
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+        if self.on_gpu:
+            fe = self.free_event[self.buf]
+            if fe is not None:                               # once per (buffer release, stream), not once per step
+                ev, seen = fe
+                cur = torch.cuda.current_stream()
+                if cur not in seen:
+                    cur.wait_event(ev)
+                    seen.add(cur)
         return self.staging[self.buf][self.fill * self.B:(self.fill + 1) * self.B]
 
     def _issue(self):
         b = self.buf
         if self.on_gpu:
+            # order the gather behind every stream that wrote a slot of this buffer: one event per such stream, recorded now
+            # (it covers everything queued on that stream so far, i.e. at least its slots)
             cur = torch.cuda.current_stream()
-            for st, ev in self.slot_events[b]:
+            for st in self.slot_streams[b]:
                 if st != cur:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
                     cur.wait_event(ev)
-            self.slot_events[b] = []
+            self.slot_streams[b] = set()
         if dist.is_initialized():
             self.pending[b] = gather_async(self.staging[b], self.recv[b], dst=self.dst)
         else:
@@ -176,20 +185,32 @@ class StagedGather:
             self.pending[1 - b].wait()        # (a stream-side wait on the NCCL backend, not a host block)
             self.pending[1 - b] = None
             if self.on_gpu:                   # ... and steps on other streams learn about it through this event
-                self.free_event[1 - b] = torch.cuda.Event()
-                self.free_event[1 - b].record()
+                ev = torch.cuda.Event()
+                ev.record()
+                self.free_event[1 - b] = (ev, {torch.cuda.current_stream()})
 
     def commit(self):
         """Call after the forward that wrote slot(), on the same stream; returns True when this step triggered a gather."""
         if self.on_gpu:
-            ev = torch.cuda.Event()
-            ev.record()
-            self.slot_events[self.buf].append((torch.cuda.current_stream(), ev))
+            self.slot_streams[self.buf].add(torch.cuda.current_stream())
         self.fill += 1
         if self.fill == self.group:
             self._issue()
             return True
         return False
+
+    def warm(self):
+        """One gather out of each staging buffer, waited for, BEFORE anything is timed: the first collective on a
+        communicator pays its one-time set-up (channels, proxy threads, kernel load: ~5 ms on a world of one) and with G steps
+        per gather a short warm-up never reaches the first gather -- round 4 measured 25 % "overhead" over 40 steps from
+        exactly that.  Leaves the object as constructed."""
+        if dist.is_initialized():
+            for b in (0, 1):
+                gather_async(self.staging[b], self.recv[b], dst=self.dst).wait()
+            if self.staging[0].is_cuda:
+                torch.cuda.synchronize(self.staging[0].device)
+        self.pending = [None, None]
+        self.buf, self.fill, self.count, self.last = 0, 0, 0, None
 
     def flush(self):
         if self.fill > 0:
