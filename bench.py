@@ -33,7 +33,10 @@ sys.path.insert(0, ROOT)
 # workers add theirs.  Measured r03 on one MI355X: under `torchrun --nproc-per-node 1` the default of 4 cost 12 % of every
 # step (0.563 vs 0.505 ms, with or without the gather) and the 4-worker pool 13 % (2,390 vs 2,740 pairs/s); 8 queues remove
 # both and leave the plain single-stream run unchanged (1,972 vs 1,975 pairs/s).  Read once, when HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Read once, when HIP initialises -- so lwsnet_amd/__init__.py exports it (and HSA_ENABLE_IPC_MODE_LEGACY=0, which RCCL needs on
+# this pool) for EVERY entry point that imports the package before touching the GPU: a driver that starts
+# `torchrun ... bench.py --gpus 8` directly gets them on every rank, as do lwsnet_amd.inference and users of model.pool().
+import lwsnet_amd    # noqa: E402,F401  (before torch initialises HIP)
 
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
@@ -181,6 +184,10 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="name=value launch-plan option (lws_set_option); experiments only")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check without a GPU: gloo, per-pair stand-in forward, value = null (tests only)")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="N > 1 ranks of the REAL HIP path sharing cuda:0 (gloo; the gather carries device maps through the host: "
+                         "RCCL refuses duplicate devices).  Exercises the N-rank code with two processes on one GPU; the ranks share "
+                         "the chip, so nothing it prints is a throughput: value = null (tests/test_gpu_dist.py)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(_self_launch(sys.argv[1:], args.gpus))
@@ -192,16 +199,18 @@ def main():
 
     global H, W
     H, W = [int(v) for v in args.size.split("x")]
-    rank, local_rank, world = ldist.init_from_env("gloo" if args.dry_run_cpu else None)
+    rank, local_rank, world = ldist.init_from_env("gloo" if (args.dry_run_cpu or args.one_gpu) else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
     if args.dry_run_cpu:
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the measured path)")
-    dev = torch.device("cuda", local_rank)
+    dev = ldist.local_device(local_rank, share_one_gpu=args.one_gpu)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
+    # scalars that cross ranks (MAX of the elapsed time): on the device for RCCL, on the host for gloo
+    red_dev = dev if (dist.is_initialized() and dist.get_backend() == "nccl") else torch.device("cpu")
 
     margs = default_args(maxdisplist=(args.maxdisp0, 5, 5), feature_fp16=args.feature_fp16)
     sd = make_state_dict(7, margs)
@@ -271,7 +280,7 @@ def main():
         step()
     if grouped:
         sg.flush()                       # ... nor a half-filled buffer of warm-up steps
-        sg.buf, sg.fill = 0, 0
+        sg.reset()
     # inside the timed region only the dominant kernel class is bracketed by hipEvents (8 events per sampled step), and only
     # on every n-th step; the per-class breakdown comes from a separate, untimed pass below.  A kernel bracketed by its own
     # events keeps its successor from being queued behind it: ~3 us per timed launch at batch 1 unprofiled, 8 us under a
@@ -296,10 +305,18 @@ def main():
     if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    gather_ok = None
+    gather_ok = all_ok = None
     if grouped and rank == 0:                            # rank 0's part of the last gather holds this rank's last stage-4 map
         mine, nvalid = sg.gathered(0)
         gather_ok = bool(torch.equal(mine[(nvalid - 1) * B:nvalid * B], pred[3]))
+        # ... and every other rank's part must be what THIS rank computes for that rank's pairs (pure batch sharding: the
+        # sharded job equals the unsharded forward bit for bit) -- untimed, world forwards on rank 0
+        all_ok = gather_ok
+        for r in range(1, world):
+            ql, qr = make_batch(B, H, W, first_index=r * B)
+            want = models[0](torch.from_numpy(ql).to(dev), torch.from_numpy(qr).to(dev))[3]
+            theirs, nv = sg.gathered(r)
+            all_ok = all_ok and nv == nvalid and bool(torch.equal(theirs[(nv - 1) * B:nv * B], want))
     tot = (ctypes.c_double * _lib.LWS_KC_COUNT)()
     cnt = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
     mid_ms, mid_n = 0.0, 0
@@ -333,7 +350,7 @@ def main():
 
         plain_steps(min(args.warmup, 3))
         t_plain = plain_steps(args.steps)
-        tt = torch.tensor([t_plain], device=dev, dtype=torch.float64)
+        tt = torch.tensor([t_plain], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_plain = float(tt.item())
         collective_overhead = {"ms_per_step_without_gather": round(1e3 * t_plain / args.steps, 4)}
@@ -370,10 +387,14 @@ def main():
         per = max(args.steps, 200) * P
         runs = []
         same = True
+        pool_mid = None
         with model.pool(workers=P) as pool:
             pool.reserve(B, H, W)
             outs = [[torch.empty((B, 1, H, W), device=dev) for _ in range(4)] for _ in range(2 * P)]
-            for rep in range(4):                       # first repetition = warm-up; three timed ones show the spread
+            for rep in range(5):                       # first repetition = warm-up; three timed ones show the spread; the
+                if rep == 4:                           # fifth (untimed) samples k_conv3d_mid16 INSIDE the pool for its roofline
+                    pool.wait_all()
+                    pool.profile(1 << KC_MID16, 4)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 jobs = []
@@ -383,13 +404,20 @@ def main():
                     jobs.append(pool.submit(left, right, out=outs[k % (2 * P)]))
                 last = [j.result() for j in jobs][-1]
                 dtp = time.perf_counter() - t1
-                if rep:
+                if 1 <= rep <= 3:
                     runs.append(B * per / dtp)
                 same = same and all(bool(torch.equal(a, b)) for a, b in zip(last, pred))
+                if rep == 4:
+                    pool.wait_all()
+                    ptot, pcnt = pool.profile_read()
+                    pool.profile(0)
+                    if pcnt[KC_MID16]:
+                        pool_mid = (1e3 * ptot[KC_MID16] / pcnt[KC_MID16], int(pcnt[KC_MID16]), B * per / dtp)
         runs.sort()
         pipelined = {"value": round(runs[len(runs) // 2], 2), "unit": "pairs/s", "workers": P, "steps": per,
                      "min": round(runs[0], 2), "max": round(runs[-1], 2), "spread_pct": round(100.0 * (runs[-1] - runs[0]) / runs[len(runs) // 2], 2),
                      "ms_per_step": round(1e3 * B / runs[len(runs) // 2], 4), "outputs_equal_single_stream": same,
+                     "_pool_mid": pool_mid,
                      "what": f"lws_pool (C ABI): {P} C++ worker threads, each with a clone of the model and ONE HIP stream, keep "
                              f"{2 * P} batch-{B} forwards in flight so that their launch-bound chains overlap on the device; median of "
                              "3 timed repetitions; not the headline: `value` is the single-stream number"}
@@ -430,7 +458,7 @@ def main():
         finally:
             model.set_option("split_bf16", 0)
     if grouped:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -474,6 +502,20 @@ def main():
                              "(profiles/r04/stamps_inkernel_clock.txt), i.e. ~140 TF sustainable",
                 "traffic": None, "flop_per_launch": flop_per_launch, "avg_launch_us": round(mid["avg_us"], 2),
                 "timed_launches": int(mid_n), "timed_every_nth_step": sample_every, "pairs_per_launch": pairs_per_launch}
+    if pipelined is not None:
+        pm = pipelined.pop("_pool_mid", None)
+        if pm is not None:
+            # k_conv3d_mid16 as it runs INSIDE the pool, beside the other workers' kernels (event-bracketed launches of a
+            # fifth, untimed repetition, every 4th forward of every worker): the same algorithmic FLOPs per launch
+            p_ach = flop_per_launch / (pm[0] * 1e-6) / 1e12
+            pipelined["roofline"] = {"bound": "mfma", "kernel": "k_conv3d_mid16<32,3,4> beside the other workers' kernels",
+                                     "achieved": round(p_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": round(p_ach / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_us": round(pm[0], 2),
+                                     "timed_launches": pm[1], "pairs_per_s_while_sampling": round(pm[2], 2),
+                                     "step_frac": round(gf_pair * pipelined["value"] / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+                                     "note": "in-pool launch duration from hipEvent pairs around the launch (not kernel timestamps): "
+                                             "co-resident kernels of other forwards stretch it; step_frac = algorithmic GF of a "
+                                             "forward x pairs/s against the same peak"}
     # the whole step against the same fp32-MFMA peak: algorithmic GF of a forward x pairs / step time.  This, not `frac`,
     # is how far the PATH is from the roofline (batch 1: 35 dependent launches, ~40 % of the step is fixed launch cost).
     step_tf = gf_pair * B / (1e3 * elapsed / args.steps) if elapsed > 0 else 0.0      # GF per ms = TF
@@ -509,8 +551,16 @@ def main():
                   (2 * 8 * h2 * w2 + 9 * h2 * w2 + h2 * w2) * 4 * B]
     # (per-step byte totals over the launches of a step: the refinement runs in chunks of pairs -- option ref_chunk_mb --, so a
     # launch of k_ref_dws covers one chunk, not the batch)
+    # Conv3D first / last layers ("un-fused activation traffic: each layer read-in + write-out"): the
+    # first layer reads the one-channel volume (stage 1 inside a forward: the two 16-channel feature maps, and writes the raw
+    # volume too) and writes C3 channels per voxel; the last layer reads C3 channels + the skip value per voxel and writes the
+    # volume (stage 1) or, with the soft-argmin fused (stages 2-3), one low-resolution map
+    hw_s = [(h2 // 4) * (w2 // 4), (h2 // 2) * (w2 // 2), h2 * w2]
+    first_bytes = sum(((2 * 16 * hw_s[0] + vox_s[0]) if si == 0 else vox_s[si]) + c3_s[si] * vox_s[si] for si in range(3)) * 4.0 * B
+    last_bytes = sum((c3_s[si] + 1) * vox_s[si] + (vox_s[si] if si == 0 else hw_s[si]) for si in range(3)) * 4.0 * B
     for name, step_bytes in (("volume_l1_warp", float(sum(warp_bytes))), ("ref_dws", 12 * 2.0 * B * H * W * 32 * 4),
-                             ("softargmin", (margs.maxdisplist[0] * (h2 // 4) * (w2 // 4) + H * W) * 4.0 * B)):
+                             ("softargmin", (margs.maxdisplist[0] * (h2 // 4) * (w2 // 4) + H * W) * 4.0 * B),
+                             ("conv3d_first", first_bytes), ("conv3d_last", last_bytes)):
         if name in kernels:
             nl = kernels[name]["launches_per_step"]
             nbytes = step_bytes / nl
@@ -594,9 +644,15 @@ def main():
     if model.get_option("mid16_form") == 1 or model.get_option("conv64_form") == 1 or model.get_option("mid8_form") == 2:
         # experiments only (--opt): the opt-in numerics mode, float32-level accuracy but not the oracle's bits
         dtype_name += " with split-bf16 MFMA operands (3 x bf16 per f32, f32 accumulate; not bit-exact against the oracle)"
+    roof = _with_traffic(roof, B, H, W, args.maxdisp0, args.feature_fp16)
+    if roof is not None:
+        # `traffic` comes from a committed rocprofv3 --pmc summary of this workload (keyed on the kernel source's sha256), never
+        # from counters read in this process; under --gpus N > 1 the object describes rank 0's launches
+        roof["traffic_measured_in_run"] = False
+        roof["rank"] = 0
     out = {
         "metric": "stereo pairs/sec @256x512 maxdisp=192 (stage-4)",
-        "value": round(pairs / elapsed, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+        "value": None if args.one_gpu else round(pairs / elapsed, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "spinup_s": round(spun_s, 3), "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": (f"BASELINE config 2: batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[24,5,5], all 4 stages"
@@ -604,7 +660,7 @@ def main():
                                 f"batch={B}/GPU, {H}x{W} synthetic pair, maxdisplist=[{args.maxdisp0},5,5], all 4 stages"),
                    "pairs_per_gpu": B, "streams": S, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4 per {G * B} pairs per rank" if grouped else "single GPU",
                    "weights": "seeded synthetic (seed 7, calibrated BN)", "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), **({"options": args.opt} if args.opt else {})},
-        "roofline": _with_traffic(roof, B, H, W, args.maxdisp0, args.feature_fp16), "secondary": secondary, "cpu_baseline": cpu, "latency_ms": latency, "pipelined": pipelined,
+        "roofline": roof, "secondary": secondary, "cpu_baseline": cpu, "latency_ms": latency, "pipelined": pipelined,
         "split_bf16": split_bf16,
         "hbm_kernels": hbm,
         "hot_path_kernel_ms_per_step": round(hot_ms, 4), "all_kernel_ms_per_step": round(all_ms, 4), "kernels": {k: {a: round(b, 2) for a, b in v.items()} for k, v in kernels.items()},
@@ -613,7 +669,11 @@ def main():
         out["collective"] = {"backend": dist.get_backend(),
                              "op": f"async gather of stage-4 maps to rank 0, one per {G} step(s) = {G * B} pairs per rank per gather",
                              "gather_every_steps": G, "gathers_in_timed_region": sg.count,
-                             "world": world, "rank0_slot_equals_local": gather_ok}
+                             "world": world, "rank0_slot_equals_local": gather_ok, "all_ranks_slots_equal_unsharded": all_ok}
+        if args.one_gpu:
+            out["shared_one_gpu"] = {"pairs_per_s_both_ranks_on_one_gpu": round(pairs / elapsed, 2),
+                                     "note": f"{world} ranks of the HIP path sharing cuda:0 over gloo (device maps gathered through the "
+                                             "host): a check of the N-rank code path, not a throughput -- value is null"}
         if collective_overhead:
             base = collective_overhead["ms_per_step_without_gather"]
             collective_overhead["overhead_pct"] = round(100.0 * (out["ms_per_step"] - base) / base, 2)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LWS_ABI_VERSION 6
+#define LWS_ABI_VERSION 7
 
 typedef enum {
     LWS_OK = 0,
@@ -240,15 +240,22 @@ int lws_pool_submit(lws_pool_handle p, const float *left, const float *right, in
                     float *const pred_out[4], void *after_stream, int64_t *ticket);
 /* Blocks the calling thread until the job's outputs are complete in device memory; returns the job's status
  * (lws_last_error() then holds the worker's message).  A ticket may be waited for any number of times while its slot is
- * live (the 4 x workers most recent tickets); for an older, recycled ticket the job is complete by construction and the
- * call returns the pool's STICKY status instead: the first failure of any job since the pool was created (or since
- * lws_pool_clear_error), so a failed forward is never reported as success once its slot has been reused.  The same sticky
+ * live (the 4 x workers most recent tickets); for an older, recycled ticket the job is complete by construction and its own
+ * status is gone: the call then returns the pool's STICKY status -- the status and message of the first job that failed since
+ * the pool was created (or since lws_pool_clear_error) -- unless the ticket is older than the SMALLEST failed ticket (those
+ * jobs ran to completion: LWS_OK), so a failed forward is never reported as success once its slot has been reused.  The same sticky
  * status is returned by lws_pool_wait_all and refuses further lws_pool_submit calls until it is cleared.
  * Options are FROZEN at lws_pool_create: the workers are clones taken then; a later lws_set_option on `model` does not reach
  * them (create a new pool after changing options). */
 int lws_pool_wait(lws_pool_handle p, int64_t ticket);
 int lws_pool_wait_all(lws_pool_handle p);
 int lws_pool_clear_error(lws_pool_handle p);          /* ABI v6 */
+/* Kernel timing inside the pool (ABI v7): lws_profile_enable(class_mask) + lws_profile_sample(every_n) on every worker's
+ * clone, and the per-class sums over the workers (arrays of LWS_KC_COUNT entries, as lws_profile_read).  Call both with
+ * nothing in flight (after lws_pool_wait_all).  bench.py prices `pipelined` with it: k_conv3d_mid16 as it runs beside the
+ * other workers' kernels. */
+int lws_pool_profile_enable(lws_pool_handle p, int class_mask, int every_n);
+int lws_pool_profile_read(lws_pool_handle p, double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus
 }

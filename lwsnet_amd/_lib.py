@@ -58,6 +58,8 @@ PROTOTYPES = {
     "lws_pool_wait": (_i, [_vp, ctypes.c_int64]),
     "lws_pool_wait_all": (_i, [_vp]),
     "lws_pool_clear_error": (_i, [_vp]),
+    "lws_pool_profile_enable": (_i, [_vp, _i, _i]),
+    "lws_pool_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), c_int64_p]),
 }
 LWS_POOL_SIDE_STREAMS = 1
 LWS_KC_COUNT = 13
@@ -75,6 +77,12 @@ def load():
     # ROCm-capable device".  With torch imported first, the SONAME libamdhip64.so.7 resolves to torch's copy and both
     # share one runtime (device pointers and streams interoperate).
     import torch  # noqa: F401
+    from . import late_env
+    if late_env():
+        import warnings
+        warnings.warn(f"lwsnet_amd was imported after HIP had initialised in this process: {', '.join(late_env())} could not be "
+                      "exported in time (import lwsnet_amd before the first torch.cuda call, or export them in the environment); "
+                      "multi-stream forwards / RCCL may run slower or fail (lwsnet_amd/__init__.py)", RuntimeWarning, stacklevel=2)
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "
@@ -84,7 +92,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lws_abi_version() != 6:
+    if lib.lws_abi_version() != 7:
         raise RuntimeError("liblwsnet_hip.so ABI version mismatch; rebuild the extension")
     _lib = lib
     return lib

@@ -89,10 +89,16 @@ static void worker_main(lws_pool *p, int wi)
             j.rc = rc;
             j.err = err;
             j.state = JOB_ISSUED;
-            if (rc != LWS_OK && p->sticky_rc == LWS_OK) {
-                p->sticky_rc = rc;
-                p->sticky_ticket = j.ticket;
-                p->sticky_err = err;
+            if (rc != LWS_OK) {
+                // workers finish out of ticket order: keep the first status and message, but the SMALLEST failed ticket, so
+                // that "tickets older than sticky_ticket ran to completion" holds with several workers
+                if (p->sticky_rc == LWS_OK) {
+                    p->sticky_rc = rc;
+                    p->sticky_ticket = j.ticket;
+                    p->sticky_err = err;
+                } else if (j.ticket < p->sticky_ticket) {
+                    p->sticky_ticket = j.ticket;
+                }
             }
         }
         p->cv_done.notify_all();
@@ -130,6 +136,7 @@ int lws_clone(lws_handle src, lws_handle *out)
     h->cfg = src->cfg;
     h->opt = src->opt;
     h->device = src->device;
+    h->cu_count = src->cu_count;         // (apply_options copies it into stage[]: a clone must not fall back to the 256 default)
     h->spec = src->spec;
     h->params = src->params;             // shared, read-only; owned by src
     h->params_bytes = src->params_bytes;
@@ -284,7 +291,7 @@ int lws_pool_wait(lws_pool_handle p, int64_t ticket)
     Job &j = p->slots[slot];
     // the slot has been recycled: that required the job to be complete; its own status is gone, the pool's first failure is not
     auto recycled = [&]() -> int {
-        // (tickets older than the FIRST failure ran to completion; anything from it on may have failed unrecorded)
+        // (tickets older than the smallest failed ticket ran to completion; anything from it on may have failed unrecorded)
         if (p->sticky_rc != LWS_OK && ticket >= p->sticky_ticket) {
             set_error("lws_pool_wait: ticket %lld has been recycled; the pool's first failed job was ticket %lld: %s",
                       (long long)ticket, (long long)p->sticky_ticket, p->sticky_err.c_str());
@@ -335,6 +342,43 @@ int lws_pool_wait_all(lws_pool_handle p)
     }
     if (first_rc != LWS_OK) set_error("%s", first_err.c_str());
     return first_rc;
+}
+
+// Per-class kernel timing of the forwards the workers run (the same hipEvent pairs lws_profile_* records for one handle):
+// enable on every worker, read the sum.  Call both with nothing in flight (lws_pool_wait_all first): the workers' records
+// are not locked against a running forward.
+int lws_pool_profile_enable(lws_pool_handle p, int class_mask, int every_n)
+{
+    LWS_CHECK_ARG(p && every_n >= 1, "lws_pool_profile_enable: bad argument");
+    for (lws_ctx *h : p->workers) {
+        int rc = lws_profile_enable(h, class_mask);
+        if (rc) return rc;
+        rc = lws_profile_sample(h, every_n);
+        if (rc) return rc;
+    }
+    return LWS_OK;
+}
+
+int lws_pool_profile_read(lws_pool_handle p, double *total_ms, int64_t *launches)
+{
+    LWS_CHECK_ARG(p && total_ms && launches, "lws_pool_profile_read: null argument");
+    int rc = pool_check_device(p, "lws_pool_profile_read");
+    if (rc) return rc;
+    for (int i = 0; i < LWS_KC_COUNT; ++i) {
+        total_ms[i] = 0.0;
+        launches[i] = 0;
+    }
+    double t[LWS_KC_COUNT];
+    int64_t n[LWS_KC_COUNT];
+    for (lws_ctx *h : p->workers) {
+        rc = lws_profile_read(h, t, n);
+        if (rc) return rc;
+        for (int i = 0; i < LWS_KC_COUNT; ++i) {
+            total_ms[i] += t[i];
+            launches[i] += n[i];
+        }
+    }
+    return LWS_OK;
 }
 
 int lws_pool_clear_error(lws_pool_handle p)

@@ -85,6 +85,16 @@ def init_from_env(backend=None, tune=True):
     return rank, local_rank, world
 
 
+def local_device(local_rank, share_one_gpu=False):
+    """The HIP device of this rank: cuda:LOCAL_RANK, or cuda:0 for every rank when the ranks deliberately share one GPU
+    (gloo only -- RCCL refuses two ranks on one device)."""
+    if share_one_gpu:
+        if dist.is_initialized() and dist.get_backend() != "gloo":
+            raise RuntimeError("ranks can share one GPU on the gloo backend only (RCCL refuses duplicate devices)")
+        return torch.device("cuda", 0)
+    return torch.device("cuda", int(local_rank))
+
+
 def shard_range(total, rank, world):
     """Contiguous, balanced split of `total` pairs: rank r takes [lo, hi)."""
     base, rem = divmod(int(total), int(world))
@@ -92,10 +102,33 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _through_host(t, group=None):
+    """True when the collective must carry a device tensor through host memory: the gloo backend has no device-side gather.
+    That combination is the debugging / single-GPU form of the N-rank job (several ranks sharing one GPU: RCCL refuses
+    duplicate devices in one communicator) -- tests/test_gpu_dist.py::test_two_ranks_on_one_gpu_*, `bench.py --one-gpu`."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+class _HostGather:
+    """Work handle of a gloo gather of device tensors: the shard went to the host on the caller's stream (synchronised),
+    gloo gathered host tensors asynchronously; wait() completes that and, on `dst`, copies the shards into the device buffers."""
+
+    def __init__(self, work, host_bufs, bufs):
+        self.work, self.host_bufs, self.bufs = work, host_bufs, bufs
+
+    def wait(self):
+        self.work.wait()
+        if self.bufs is not None:
+            for d, h in zip(self.bufs, self.host_bufs):
+                d.copy_(h, non_blocking=False)
+        return True
+
+
 def gather_pairs(local, counts=None, dst=0, group=None):
     """Gathers per-rank disparity maps [b_r,1,H,W] to `dst` (concatenated in rank order); other ranks get None.
 
-    Equal shards use one `gather`; ragged shards are padded to the largest shard first."""
+    Equal shards use one `gather`; ragged shards are padded to the largest shard first.  On the gloo backend device tensors
+    travel through host memory (`_through_host`) and come back as a device tensor on `dst`."""
     if not dist.is_initialized():
         return local
     world, rank = dist.get_world_size(group), dist.get_rank()        # (global rank: `dst` is one)
@@ -107,11 +140,14 @@ def gather_pairs(local, counts=None, dst=0, group=None):
         pad = torch.zeros((bmax - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         send = torch.cat([local, pad], 0)
     send = send.contiguous()
+    device = send.device
+    if _through_host(send, group):
+        send = send.cpu()                                  # (synchronises the stream that produced the shard)
     bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     dist.gather(send, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0).to(device)
 
 
 def gather_async(local, bufs, dst=0, group=None):
@@ -119,7 +155,12 @@ def gather_async(local, bufs, dst=0, group=None):
     (`bufs`: list of world tensors there, None elsewhere), asynchronous -- RCCL runs it on its own stream behind this
     step's kernels so it overlaps the next step.  Returns the work handle (wait() before reading `bufs`)."""
     # `dst` of dist.gather is a GLOBAL rank: compare with the global rank, not the group-local one
-    return dist.gather(local.contiguous(), bufs if dist.get_rank() == dst else None, dst=dst, group=group, async_op=True)
+    root = dist.get_rank() == dst
+    if _through_host(local, group):
+        send = local.contiguous().cpu()
+        host = [torch.empty_like(send) for _ in bufs] if root else None
+        return _HostGather(dist.gather(send, host, dst=dst, group=group, async_op=True), host, bufs if root else None)
+    return dist.gather(local.contiguous(), bufs if root else None, dst=dst, group=group, async_op=True)
 
 
 class StagedGather:
@@ -213,12 +254,27 @@ class StagedGather:
         self.buf, self.fill, self.count, self.last = 0, 0, 0, None
 
     def flush(self):
+        """Gathers a partly filled buffer and waits (stream-side on NCCL) for everything in flight.  Both staging buffers are
+        free afterwards; with `multi_stream` steps on other streams learn that through `free_event`, exactly as after
+        `_issue` (flush() used to order the current stream only, so a step on another stream could overwrite a
+        slot its tail gather was still reading)."""
         if self.fill > 0:
             self._issue()
         for i, w in enumerate(self.pending):
             if w is not None:
                 w.wait()
                 self.pending[i] = None
+                if self.on_gpu:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self.free_event[i] = (ev, {torch.cuda.current_stream()})
+
+    def reset(self):
+        """After flush(): start filling at slot 0 of buffer 0 again and zero the gather count (bench.py between the warm-up
+        and the timed region).  Pending free events stay in force."""
+        if self.fill or any(w is not None for w in self.pending):
+            raise RuntimeError("StagedGather.reset() needs a flush() first")
+        self.buf, self.fill, self.count = 0, 0, 0
 
     def gathered(self, rank):
         """On `dst` after flush(): (tensor [group*B,1,H,W] of `rank`'s most recent gather, number of valid steps in it)."""

@@ -260,8 +260,14 @@ class ForwardPool:
             _lib.check(self._lib.lws_pool_submit(self._p, ctypes.c_void_p(left.data_ptr()), ctypes.c_void_p(right.data_ptr()),
                                                  B, H, W, ptrs, after, ctypes.byref(ticket)), "lws_pool_submit")
         # the pool itself keeps the inputs and outputs alive until the ticket has completed: a job object dropped without
-        # result() must not hand its tensors back to the caching allocator while a worker's stream still uses them
+        # result() must not hand its tensors back to the caching allocator while a worker's stream still uses them.
+        # lws_pool_submit recycles the slot of ticket t - 4 x workers only after hipEventSynchronize on that job, so every
+        # ticket that old has left the device: a caller that never waits (fire-and-forget into `out`) does not grow this map
         self._live[ticket.value] = (left, right, outs)
+        horizon = ticket.value - 4 * self.workers
+        if horizon >= 0 and len(self._live) > 4 * self.workers:
+            for t in [t for t in self._live if t <= horizon]:
+                del self._live[t]
         return _PoolJob(self, ticket.value, (left, right), outs)
 
     def _wait(self, ticket):
@@ -275,6 +281,18 @@ class ForwardPool:
             _lib.check(self._lib.lws_pool_wait_all(self._p), "lws_pool_wait_all")
         finally:
             self._live.clear()
+
+    def profile(self, class_mask, every_n=1):
+        """Per-class kernel timing on every worker (lws_pool_profile_enable); call with nothing in flight."""
+        _lib.check(self._lib.lws_pool_profile_enable(self._p, int(class_mask), int(every_n)), "lws_pool_profile_enable")
+
+    def profile_read(self):
+        """(total_ms[class], launches[class]) summed over the workers; call with nothing in flight."""
+        tot = (ctypes.c_double * _lib.LWS_KC_COUNT)()
+        cnt = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
+        with torch.cuda.device(self._model.device):
+            _lib.check(self._lib.lws_pool_profile_read(self._p, tot, cnt), "lws_pool_profile_read")
+        return list(tot), list(cnt)
 
     def clear_error(self):
         """Clears the pool's sticky first-failure status (lws_pool_clear_error) so that submits are accepted again."""

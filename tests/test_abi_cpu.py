@@ -26,7 +26,7 @@ def test_header_and_prototypes_agree():
 def test_library_exports_every_symbol(hip_lib):
     for name in _declared():
         assert hasattr(hip_lib, name), name
-    assert hip_lib.lws_abi_version() == 6
+    assert hip_lib.lws_abi_version() == 7
 
 
 def _create(lib, **kw):

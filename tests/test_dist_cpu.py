@@ -73,3 +73,37 @@ def test_sharded_gather_equals_unsharded(B):
 def test_gather_is_identity_without_process_group():
     x = torch.ones(2, 1, 4, 4)
     assert gather_pairs(x) is x
+
+
+def test_staged_gather_flush_then_reset():
+    """StagedGather.reset() (callers used to poke buf / fill): refuses while slots are filled, and after flush()
+    starts at slot 0 of buffer 0 with a zero gather count.  No process group: the 'gather' is a copy on this rank."""
+    from lwsnet_amd.dist import StagedGather
+    sg = StagedGather(1, 4, 8, 3, torch.device("cpu"))
+    for k in range(4):
+        sg.slot().fill_(float(k))
+        sg.commit()
+    assert sg.count == 1 and sg.fill == 1
+    with pytest.raises(RuntimeError, match="flush"):
+        sg.reset()
+    sg.flush()
+    got, nvalid = sg.gathered(0)
+    assert sg.count == 2 and nvalid == 1 and float(got[0, 0, 0, 0]) == 3.0
+    sg.reset()
+    assert (sg.buf, sg.fill, sg.count) == (0, 0, 0)
+
+
+def test_package_import_exports_the_runtime_switches():
+    """lwsnet_amd/__init__.py: GPU_MAX_HW_QUEUES and HSA_ENABLE_IPC_MODE_LEGACY are exported by ANY import of the package
+    (bench.py used to be the only entry point that set them), the caller's values win, and an import after
+    HIP is up is reported by late_env()."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import os, sys; sys.path.insert(0, %r); import lwsnet_amd.dist, lwsnet_amd; "
+            "print(os.environ['GPU_MAX_HW_QUEUES'], os.environ['HSA_ENABLE_IPC_MODE_LEGACY'], lwsnet_amd.late_env())" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and out.stdout.split()[:2] == ["8", "0"] and out.stdout.strip().endswith("[]"), (out.stdout, out.stderr)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, GPU_MAX_HW_QUEUES="4"), timeout=300)
+    assert out.stdout.split()[:2] == ["4", "0"], (out.stdout, out.stderr)

@@ -32,6 +32,50 @@ def test_nccl_world1_sharded_forward_bitwise(hip_lib):
     assert "OK nccl world_size=1" in p.stdout
 
 
+def _spawn_ranks(script, world, timeout=900):
+    port = str(_port())
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", script), str(r), str(world), port],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_env(), cwd=ROOT) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                        # (the exact children started above)
+    return procs, outs
+
+
+def test_two_ranks_on_one_gpu_sharded_forward_bitwise(hip_lib):
+    """VERDICT r4 item 1 / SURVEY.md section 8(e) "Test without 8 GPUs": TWO processes on the real HIP path (both on cuda:0,
+    gloo -- RCCL refuses duplicate devices), `sharded_forward` on each; rank 0 asserts the gathered stage-4 maps equal the
+    unsharded `model(left, right)[3]` bit for bit for B = 4, ragged B = 5 (64x256) and 2 x (8 x 256x512), BASELINE config 4's
+    per-rank shape; the staged gather of bench.py through the same two processes.  What stays unmeasured on this pool: the
+    xGMI hop and the peers' clocks."""
+    procs, outs = _spawn_ranks("gloo_world2_child.py", 2)
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, (so[-1500:], se[-3000:])
+    assert "OK gloo world_size=2 on one GPU" in outs[0][0]
+
+
+def test_bench_two_ranks_on_one_gpu(hip_lib):
+    """`bench.py --gpus 2 --one-gpu --batch 8`: the driver's N > 1 launch shape (self-started torch.distributed.run, two
+    ranks, per-rank shard of seeded pairs, staged gather to rank 0, barrier-bracketed clock, MAX over ranks) on the HIP path
+    with both ranks sharing cuda:0.  The ranks share one chip, so the line carries no throughput: value is null."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-gpu", "--batch", "8", "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] is None and d["collective"]["backend"] == "gloo" and d["collective"]["world"] == 2
+    assert d["collective"]["rank0_slot_equals_local"] is True and d["collective"]["all_ranks_slots_equal_unsharded"] is True
+    assert d["shared_one_gpu"]["pairs_per_s_both_ranks_on_one_gpu"] > 0
+    assert d["roofline"]["rank"] == 0 and d["roofline"]["traffic_measured_in_run"] is False
+
+
 def test_bench_under_torchrun_world1(hip_lib):
     """bench.py as the driver launches it for N > 1, with N = 1: communicator, per-step async gather of the stage-4
     maps on device memory, barrier-bracketed clock, MAX all-reduce -- one JSON line from rank 0."""

@@ -520,6 +520,46 @@ def test_pool_reports_a_workers_error_at_wait(dev, model, hip_lib):
                 pool.submit(lt, rt, out=bad)
 
 
+def test_pool_two_failures_two_workers_keep_the_smallest_ticket(dev, model, hip_lib):
+    """with two workers, jobs fail in completion order, not ticket order.  Two failing jobs submitted back to back:
+    both waits report the failure, and the pool's sticky ticket (named by the refusal of the next submit) is the SMALLER of the
+    failed tickets whichever worker finished first -- so `lws_pool_wait` on a recycled ticket older than it may say LWS_OK.
+    Also: fire-and-forget submits do not grow ForwardPool._live without bound."""
+    import ctypes
+    import re
+    from lwsnet_amd import _lib
+    left, right = make_batch(1, 64, 256, 5)
+    lt, rt = cu(left, dev), cu(right, dev)
+    bad = torch.zeros((1, 3, 30, 256), device=dev)
+    outs = [[torch.empty((1, 1, 64, 256), device=dev) for _ in range(4)] for _ in range(2)]
+    for attempt in range(4):
+        with model.pool(workers=2) as pool:
+            pool.reserve(1, 64, 256)
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            tickets = []
+            for o in outs:
+                t = ctypes.c_int64(-1)
+                ptrs = (ctypes.c_void_p * 4)(*[x.data_ptr() for x in o])
+                rc = hip_lib.lws_pool_submit(pool._p, ctypes.c_void_p(bad.data_ptr()), ctypes.c_void_p(bad.data_ptr()), 1, 30, 256,
+                                             ptrs, stream, ctypes.byref(t))
+                if rc != 0:                        # the first failure was recorded before the second submit: refused, try again
+                    break
+                tickets.append(t.value)
+            if len(tickets) < 2:
+                continue
+            assert all(hip_lib.lws_pool_wait(pool._p, ctypes.c_int64(t)) == _lib.LWS_ERR_INVALID for t in tickets)
+            with pytest.raises(ValueError, match="earlier job") as ei:
+                pool.submit(lt, rt)
+            assert int(re.search(r"ticket (\d+)", str(ei.value)).group(1)) == min(tickets)
+            break
+    with model.pool(workers=2) as pool:
+        for _ in range(40):
+            pool.submit(lt, rt, out=outs[0])       # never waited for
+            assert len(pool._live) <= 4 * pool.workers + 1
+        pool.wait_all()
+        assert not pool._live
+
+
 def test_clone_shares_parameters(dev, model, hip_lib):
     """lws_clone: a second handle on the same parameter slab; it refuses set_tensor / finalize and returns the same bits."""
     import ctypes
@@ -789,12 +829,22 @@ def test_forward_matches_literal_oracle(dev, model):
     assert len(pred) == 4 and all(tuple(p.shape) == (1, 1, 64, 256) and p.dtype == torch.float32 for p in pred)
     err = [float(np.abs(pred[s].cpu().numpy() - g[f"pred{s}"]).max()) for s in range(4)]
     print("max-abs vs literal oracle per stage:", err)
-    assert err[0] < 1e-3, err                       # north_star tolerance at the stage the noise has not amplified
-    # stages 2-4: 1.5 x the distances measured for this fixture (2.0e-4 / 8.9e-4 / 3.5e-3 / 3.4e-3 px; the HIP result is the
-    # C oracle's bit for bit, so they are constants of the arithmetic contract, not run-to-run quantities).  They sit on
-    # the float32 noise floor of the reference algorithm, above north_star's 1e-3 px at stages 3-4.
-    for s_, bound in enumerate((3.0e-4, 1.4e-3, 5.3e-3, 5.1e-3)):
-        assert err[s_] < bound, (s_, err)
+    assert err[0] < 1e-3, err                       # north_star's tolerance, met to the letter at stage 1 only
+    # Stages 2-4: the bound is DERIVED from the committed float64 fixture of the same pair, not from this
+    # build's history.  tests/golden/ref_source_e2e_64x256.npz holds the reference source's float32 AND float64 stage maps
+    # (its float32 maps are the literal oracle's bit for bit, asserted below); floor_s = |float32 - float64| is the noise
+    # floor of the reference algorithm's own float32 arithmetic (2.1e-4 / 9.5e-4 / 2.7e-3 / 2.7e-3 px here).  Two float32
+    # evaluations that each sit within floor_s of the float64 truth differ by at most 2 x floor_s; a numerics change that
+    # moves the build further than that from the literal oracle is outside the reference's own noise and fails here.
+    # north_star's 1e-3 px is below floor_s at stages 3-4: no float32 implementation can promise it.
+    r = golden("ref_source_e2e_64x256.npz")
+    assert np.array_equal(r["left"], g["left"]) and all(np.array_equal(r[f"pred{s}"], g[f"pred{s}"]) for s in range(4))
+    floor = [float(np.abs(r[f"pred{s}"].astype(np.float64) - r[f"pred64_{s}"]).max()) for s in range(4)]
+    print("float32 noise floor of the reference algorithm per stage:", floor)
+    for s_ in range(4):
+        assert err[s_] <= 2.0 * floor[s_], (s_, err, floor)
+        mine64 = float(np.abs(pred[s_].cpu().numpy().astype(np.float64) - r[f"pred64_{s_}"]).max())
+        assert mine64 <= 1.25 * floor[s_] + 1e-4, (s_, mine64, floor)       # the gate smoke() and DESIGN.md section 2 state
     from oracle.lws_oracle import error_3px
     assert error_3px(pred[3].cpu().numpy(), np.maximum(g["pred3"], 1e-3)) == 0.0
 
