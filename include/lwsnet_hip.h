@@ -172,6 +172,13 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *                    64-pixel row segment (all channels, zero-filled outside the image) in LDS and computes the 2m - 1
  *                    hypotheses from it; 0 = every tap gathered from global memory (the form a tile falls back to when its
  *                    flow range needs more than 160 window columns)
+ *   "fuse_last1"     1 (default) / 0: batches <= 2 (with "defer_upsample"): stage 1's last Conv3D layer and the soft-argmin run in
+ *                    one launch (24 x 2 x 4 tiles spanning D) and NO launch materialises pred1: stage 2's warp kernel evaluates
+ *                    the taps it needs from the 1/8 map, stage 3's warp kernel writes pred1 beside pred2 (round 5: one launch
+ *                    less on the batch-1 chain); 0 = k_conv3d_last + k_softargmin_upsample
+ *   "side_xcds"      0 (default) / 1..7: the handle's side stream (feature-extractor tail, refinement1_left, alternate
+ *                    refinement chunks) is a CU-masked stream confined to that many of the 8 XCDs (the last n), so that its
+ *                    HBM-bound kernels do not share CUs with the caller's stream's MFMA kernels on the other XCDs (round 5)
  *   "device"         the HIP device the handle belongs to; settable only before lws_finalize / lws_reserve allocate
  * Unknown names and out-of-range values return LWS_ERR_INVALID. */
 int lws_set_option(lws_handle h, const char *name, int value);

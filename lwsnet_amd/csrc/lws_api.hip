@@ -574,6 +574,12 @@ static int refine_left_chunk(lws_ctx *h, const float *left, int B, int H, int W,
 // writes the map out as a by-product, since it is an output of the path.
 struct DeferState {
     bool allow_last = false;                 // the caller will consume pred_out[2] through refine_rest
+    // stage 1 (round 5, batches <= 2): the last Conv3D layer + soft-argmin leave low[0] (def[0]) and NO launch materialises
+    // pred1: stage 2's warp kernel evaluates the four taps it needs from low[0]; stage 3's warp kernel, which evaluates and
+    // writes the deferred stage-2 map pred2 = upsample(low[1]) + pred1 on its 2 x 2 blocks, evaluates pred1 =
+    // upsample(low[0]) at the same pixels and writes it out too (two-level DeferredMap).  pred1_unwritten: nobody has yet.
+    bool allow_first = false;                // the caller runs the whole forward (lws_forward)
+    bool pred1_unwritten = false;
     bool def[3] = {false, false, false};
     const float *low[3] = {nullptr, nullptr, nullptr};
     int lh[3] = {0, 0, 0}, lw[3] = {0, 0, 0};
@@ -679,6 +685,14 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
     DeferState local;
     if (ds == nullptr) ds = &local;
     static const int feat_c[3] = {16, 16, 8};   // feature_extraction outputs, submodules.py:101,104,186
+    // pred_out[0] as memory (k_upsample_add's `prev`): when stage 1 left its map deferred and the consumer that would have
+    // written it out (stage 3's warp kernel on a deferred stage-2 map) is not coming, one k_upsample_add materialises it
+    auto need_pred1 = [&]() -> int {
+        if (!ds->pred1_unwritten) return LWS_OK;
+        ds->pred1_unwritten = false;
+        ProfScope p(h, LWS_KC_UPSAMPLE, st);
+        return launch_upsample_add(ds->low[0], nullptr, pred_out[0], B, ds->lh[0], ds->lw[0], H, W, st);       // :145-148
+    };
     for (int s = 0; s < 3; ++s) {
         int D, hh, ww;
         stage_dims(h, s, H, W, D, hh, ww);
@@ -696,11 +710,17 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
             ProfScope p(h, LWS_KC_VOLUME_SHIFT, st);
             rc = launch_volume_l1_shift(featsL[0], featsR[0], raw, B, feat_c[0], hh, ww, D, st, h->cfg.feature_fp16 != 0);   // :131
         } else if (ds->def[s - 1]) {
-            // pred_out[s-1] is deferred: read it as upsample(low[s-1]) + pred_out[s-2] and write it out
+            // pred_out[s-1] is deferred: read it as upsample(low[s-1]) + pred_out[s-2] and (s == 2) write it out.  s == 1: stage
+            // 1's map has no predecessor and is not written here; s == 2 with pred1 still unwritten: pred1 = upsample(low[0]) is
+            // evaluated at the same pixels and written out as well
+            const bool two = s == 2 && ds->pred1_unwritten;
             ProfScope p(h, LWS_KC_VOLUME_WARP, st);
-            rc = launch_volume_l1_warp(featsL[s], featsR[s], pred_out[s - 2], raw, nullptr, B, feat_c[s], hh, ww, H, W,
-                                       h->cfg.maxdisplist[s], st, h->cfg.feature_fp16 != 0, ds->low[s - 1], ds->lh[s - 1],
-                                       ds->lw[s - 1], pred_out[s - 1], h->opt.warp_form);
+            rc = launch_volume_l1_warp(featsL[s], featsR[s], (s == 1 || two) ? nullptr : pred_out[s - 2], raw, nullptr, B, feat_c[s],
+                                       hh, ww, H, W, h->cfg.maxdisplist[s], st, h->cfg.feature_fp16 != 0, ds->low[s - 1],
+                                       ds->lh[s - 1], ds->lw[s - 1], s == 2 ? pred_out[s - 1] : nullptr, h->opt.warp_form,
+                                       two ? ds->low[0] : nullptr, two ? ds->lh[0] : 0, two ? ds->lw[0] : 0,
+                                       two ? pred_out[0] : nullptr);
+            if (two) ds->pred1_unwritten = false;
         } else {
             ProfScope p(h, LWS_KC_VOLUME_WARP, st);
             rc = launch_volume_l1_warp(featsL[s], featsR[s], pred_out[s - 1], raw, nullptr, B, feat_c[s], hh, ww, H, W,
@@ -710,10 +730,28 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         if (rc) return rc;
         const float start = s == 0 ? 0.0f : (float)(-h->cfg.maxdisplist[s] + 1);
         bool fused = false;
-        rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st, low, start, &fused, first_done);  // :136-138
+        // stage 1: the fused last layer only pays when the full-resolution map can leave the chain (below); otherwise the
+        // k_softargmin_upsample launch does soft-argmin AND upsample in one kernel
+        const bool defer_first = s == 0 && defer_up && h->opt.fuse_last1 != 0 && ds->allow_first && B <= 2 && H % 2 == 0 && W % 2 == 0;
+        rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st, (s > 0 || defer_first) ? low : nullptr, start, &fused,
+                          first_done);                                                                      // :136-138
         if (rc) return rc;
         if (s == 0 && after_stage1_stack) {
             rc = after_stage1_stack();
+            if (rc) return rc;
+        }
+        if (s == 0 && fused) {
+            ds->def[0] = true;
+            ds->low[0] = low;
+            ds->lh[0] = hh;
+            ds->lw[0] = ww;
+            ds->pred1_unwritten = true;
+            continue;
+        }
+        const bool defer_this = fused && defer_up && B <= 2 && H % 2 == 0 && W % 2 == 0 && (s == 1 || (s == 2 && ds->allow_last));
+        if (s >= 1 && !(s == 1 && defer_this)) {
+            // a launch below reads pred_out[0] (s == 1), or the path is about to end (s == 2) with pred1 still unwritten
+            rc = need_pred1();
             if (rc) return rc;
         }
         if (!fused) {
@@ -739,7 +777,7 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         // (measured r01: two launches fewer are worth +0.5 % at batch 1; at batch 8 the heavier consumers cost 1.2 %, so
         // large batches keep the separate k_upsample_add launches)
         // (only at exact 2x geometry: with odd H or W the four taps of a stage-3 pixel are not the 2x2 block it owns)
-        if (defer_up && B <= 2 && H % 2 == 0 && W % 2 == 0 && (s == 1 || (s == 2 && ds->allow_last))) {
+        if (defer_this) {
             ds->def[s] = true;
             ds->low[s] = low;
             ds->lh[s] = hh;
@@ -783,11 +821,32 @@ static int check_device(const lws_ctx *h, const char *what)
 
 // side streams and cross-stream events of lws_forward: created by lws_reserve (which promises that later calls allocate
 // nothing) or, for callers that never reserve, on the first forward
+// Option "side_xcds" = n in 1..7: the side stream may only use the CUs of n of the 8 XCDs (hipExtStreamCreateWithCUMask).  The
+// mask's bit i is CU slot i / 8 of XCD i % 8 on this part (tools/micro/cumask.hip prints the map), so whole XCDs are the bits
+// with i % 8 >= 8 - n.  0 = no mask (the default).
+static int create_side_stream(lws_ctx *h, hipStream_t *out)
+{
+    const int n = h->opt.side_xcds;
+    if (n <= 0 || n >= 8) {
+        LWS_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+        return LWS_OK;
+    }
+    const int ncu = h->cu_count > 0 ? h->cu_count : 256;
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int i = 0; i < ncu; ++i)
+        if (i % 8 >= 8 - n) mask[(size_t)i / 32] |= 1u << (i % 32);
+    LWS_HIP(hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()));
+    return LWS_OK;
+}
+
 static int ensure_streams(lws_ctx *h)
 {
     if (h->side) return LWS_OK;
     const unsigned ef = hipEventDisableTiming | hipEventDisableSystemFence;
-    LWS_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    {
+        const int rc = create_side_stream(h, &h->side);
+        if (rc) return rc;
+    }
     LWS_HIP(hipEventCreateWithFlags(&h->ev_fork, ef));
     LWS_HIP(hipEventCreateWithFlags(&h->ev_join, ef));
     for (int i = 0; i < 3; ++i) LWS_HIP(hipEventCreateWithFlags(&h->ev_feat[i], ef));
@@ -866,6 +925,8 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"ref_pipe", &h->opt.ref_pipe},
                                                      {"warp_form", &h->opt.warp_form},
                                                      {"mid8_balance", &h->opt.mid8_balance},
+                                                     {"side_xcds", &h->opt.side_xcds},
+                                                     {"fuse_last1", &h->opt.fuse_last1},
                                                      {"device", &h->device},
                                                      {"mid8_form", &h->opt.mid8_form}};
     for (auto &e : tab)
@@ -901,6 +962,19 @@ int lws_set_option(lws_handle h, const char *name, int value)
     }
     else if (strcmp(name, "mid8_form") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 2, "lws_set_option: mid8_form must be 0, 1 or 2 (got %d)", value);
+    else if (strcmp(name, "side_xcds") == 0) {
+        LWS_CHECK_ARG(value >= 0 && value <= 7, "lws_set_option: side_xcds must be in 0..7 (got %d)", value);
+        if (h->side != nullptr && value != h->opt.side_xcds) {
+            // the mask is a property of the stream: replace the side stream (nothing of this handle may be in flight)
+            LWS_CHECK_DEVICE(h, "lws_set_option(side_xcds)");
+            LWS_HIP(hipStreamSynchronize(h->side));
+            LWS_HIP(hipStreamDestroy(h->side));
+            h->side = nullptr;
+            h->opt.side_xcds = value;
+            const int rc = create_side_stream(h, &h->side);
+            if (rc) return rc;
+        }
+    }
     else
         LWS_CHECK_ARG(value == 0 || value == 1, "lws_set_option: %s must be 0 or 1 (got %d)", name, value);
     *slot = value;
@@ -1328,6 +1402,7 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     };
     DeferState ds;
     ds.allow_last = refine_can_defer(h);
+    ds.allow_first = true;
     rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st, multi ? h->ev_feat : nullptr, launch_tail, &ds);   // :115-156
     if (rc) return rc;
     if (multi) LWS_HIP(hipStreamWaitEvent(st, h->ev_join, 0));

@@ -184,6 +184,8 @@ struct lws_ctx {
         int ref_pipe = -1;         // refinement chunks alternating over two streams: -1 = from four chunks up, 0 = never, 1 = from two chunks up
         int mid8_balance = 1;      // k_conv3d_mid8q: small grids take small tiles with the residency capped so that every CU gets the same number
         int warp_form = 1;         // residual volumes: 1 = right-feature window of a 64-pixel row segment staged in LDS, 0 = every tap gathered from global memory
+        int fuse_last1 = 1;        // batches <= 2: stage 1's last Conv3D layer + soft-argmin in one launch, pred1 evaluated by its consumers
+        int side_xcds = 0;         // 1..7: the side stream is confined to the CUs of that many XCDs (CU-masked stream); 0 = unmasked
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
     } opt;
     unsigned prof_mask = 0;                  // kernel classes being timed in the current call
@@ -224,7 +226,8 @@ int launch_volume_l1_shift(const float *L, const float *R, float *cost, int B, i
 int launch_volume_l1_warp(const float *L, const float *R, const float *prev, float *cost, float *wflow_out,
                           int B, int C, int h, int w, int H, int W, int m, hipStream_t st, bool q16 = false,
                           const float *plow = nullptr, int ph = 0, int pw = 0, float *pmat = nullptr,     // deferred prev map
-                          int form = 1);   // 1 = right-feature window staged in LDS, 0 = every tap gathered from global memory
+                          int form = 1,    // 1 = right-feature window staged in LDS, 0 = every tap gathered from global memory
+                          const float *plow0 = nullptr, int ph0 = 0, int pw0 = 0, float *pmat0 = nullptr);   // prev == nullptr: its own deferred source
 int launch_softargmin(const float *cost, float *low, int B, int D, int h, int w, float start, hipStream_t st);
 int launch_upsample_add(const float *low, const float *prev, float *out, int B, int h, int w, int H, int W,
                         hipStream_t st);

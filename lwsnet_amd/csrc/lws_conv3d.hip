@@ -1249,7 +1249,7 @@ struct LastCfg {
     static constexpr int NVOX = HD * HY * HX;
     static constexpr int ITEMS = NVOX * (C3 / 4);
     static constexpr int SITER = (ITEMS + NT - 1) / NT;
-    static constexpr int LDS_FLOATS = NVOX * VS + (FUSE ? NOUT : 0);
+    static constexpr int LDS_FLOATS = NVOX * VS + (FUSE ? 2 * NOUT : 0);
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 };
 
@@ -1319,11 +1319,40 @@ __global__ __launch_bounds__((LastCfg<C3, TD, TY, TX, FUSE>::NT)) void k_conv3d_
         }
     }
     if (FUSE) {
-        float *sC = lds + Cfg::NVOX * VS;            // [TD][TY*TX]
+        // Soft-argmin over the TD == D costs of each of the tile's TY*TX pixels, all NOUT threads working (round 5; until then
+        // the TY*TX threads of plane 0 each ran the three serial passes of softargmin_pixel -- 27 to 72 dependent lws_expf
+        // calls at the end of every workgroup).  The operations and their order are softargmin_pixel's: m = max_k(-c_k);
+        // e_k = lws_expf(-c_k - m) -- one per thread; S = e_0 + e_1 + ... ascending; t_k = (e_k / S) * (start + k) -- one per
+        // thread; result = t_0 + t_1 + ... ascending.  Only the two sums are serial (D additions each).
+        constexpr int P = TY * TX;
+        float *sC = lds + Cfg::NVOX * VS;            // [TD][P]: the costs, later the terms t_k
+        float *sE = sC + Cfg::NOUT;                  // [TD][P]: e_k
+        const int pix = tid % P;                     // (tid = ld * P + pix; for tid >= NOUT nothing below is used)
         if (tid < Cfg::NOUT) sC[tid] = val;
         __syncthreads();
-        if (tid < TY * TX && gy < h && gx < w)       // ld == 0 for these threads: gd = d0 = 0, TD == D
-            low[((int64_t)b * h + gy) * w + gx] = softargmin_pixel(sC + tid, TY * TX, TD, start);
+        float e = 0.0f;
+        if (tid < Cfg::NOUT) {
+            float m = -sC[pix];
+#pragma unroll
+            for (int k = 1; k < TD; ++k) m = fmaxf(m, -sC[k * P + pix]);
+            e = lws_expf(-val - m);
+            sE[tid] = e;
+        }
+        __syncthreads();
+        if (tid < Cfg::NOUT) {
+            float S = 0.0f;
+#pragma unroll
+            for (int k = 0; k < TD; ++k) S = S + sE[k * P + pix];
+            const float pk = e / S;
+            sC[tid] = pk * (start + (float)ld);
+        }
+        __syncthreads();
+        if (tid < P && gy < h && gx < w) {           // ld == 0 for these threads: gd = d0 = 0, TD == D
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < TD; ++k) acc = acc + sC[k * P + tid];
+            low[((int64_t)b * h + gy) * w + gx] = acc;
+        }
     }
 }
 
@@ -1674,13 +1703,20 @@ int launch_conv3d_last(const Stage3d &s, const float *act_in, const float *cost_
 }
 
 // Last layer + soft-argmin in one launch; available when the tile can span the disparity axis.
-bool conv3d_last_can_fuse(const Stage3d &s, int D) { return D == 9 && (s.c3 == 8 || s.c3 == 16); }
+// (C3 = 32 with D = 24 / 32 -- stage 1 of the default and of the maxdisp-256 configuration -- since round 5: a 24 x 2 x 4
+// tile, 26 x 4 x 6 halo voxels = 90 KB of LDS, one workgroup per CU; one 256x512 pair is exactly 256 such tiles)
+bool conv3d_last_can_fuse(const Stage3d &s, int D)
+{
+    return (D == 9 && (s.c3 == 8 || s.c3 == 16)) || (s.c3 == 32 && (D == 24 || D == 32));
+}
 
 int launch_conv3d_last_softargmin(const Stage3d &s, const float *act_in, const float *cost_skip, float *cost_out,
                                   float *low, float start, int B, int D, int h, int w, hipStream_t st)
 {
     if (D == 9 && s.c3 == 8) return last_launch<8, 9, 2, 16, true>(s, act_in, cost_skip, cost_out, low, start, B, D, h, w, st);
     if (D == 9 && s.c3 == 16) return last_launch<16, 9, 2, 16, true>(s, act_in, cost_skip, cost_out, low, start, B, D, h, w, st);
+    if (D == 24 && s.c3 == 32) return last_launch<32, 24, 2, 4, true>(s, act_in, cost_skip, cost_out, low, start, B, D, h, w, st);
+    if (D == 32 && s.c3 == 32) return last_launch<32, 32, 2, 4, true>(s, act_in, cost_skip, cost_out, low, start, B, D, h, w, st);
     set_error("conv3d_last_softargmin: no fused variant for c3=%d D=%d", s.c3, D);
     return LWS_ERR_INVALID;
 }

@@ -144,70 +144,80 @@ __device__ __forceinline__ void src_index(int dst, float ratio, int in, int &i0,
 // A "deferred" full-resolution disparity map: pred(Y,X) = upsample(low * H / h)(Y,X) + prev(Y,X) evaluated on demand
 // with exactly the operations of k_upsample_add (models.py:145-148,153-156), so a consumer can read the map before
 // the kernel that materialises it has run.  low == nullptr: the map is materialised, read prev directly.
+// Two levels (round 5): when prev == nullptr and low0 != nullptr the previous map is itself deferred and has no
+// predecessor -- prev(Y,X) = upsample(low0 * H / h0)(Y,X), stage 1's map seen from stage 3; prev == nullptr and
+// low0 == nullptr: there is no previous map (stage 1's map seen from stage 2), nothing is added.
 struct DeferredMap {
     const float *low;     // [h,w] of this image, or nullptr
-    const float *prev;    // [H,W] of this image (the previous stage's map; the materialised map if low == nullptr)
+    const float *prev;    // [H,W] of this image (the previous stage's map; the materialised map if low == nullptr), or nullptr
     int h, w;
     float mul_a, mul_b;   // (float)H, 1/(float)h
+    const float *low0 = nullptr;   // [h0,w0]: the previous map's own low-resolution source (see above)
+    int h0 = 0, w0 = 0;
+    float mul_b0 = 0.0f;           // 1/(float)h0
 };
 
-__device__ __forceinline__ float deferred_at(const DeferredMap &m, int y, int x, int H, int W)
+// upsample(low * mul_a * mul_b) at N points, every load issued before the first use: k_upsample_add's operations
+template <int N>
+__device__ __forceinline__ void upsample_at_n(const float *low, int h, int w, float mul_a, float mul_b, const int (&ys)[N],
+                                              const int (&xs)[N], int H, int W, float (&out)[N])
 {
-    const float pv = m.prev[(int64_t)y * W + x];
-    if (m.low == nullptr) return pv;
-    const float rh = (float)m.h / (float)H, rw = (float)m.w / (float)W;
-    int y0, y1, x0, x1;
-    float hy0, hy1, wx0, wx1;
-    src_index(y, rh, m.h, y0, y1, hy0, hy1);
-    src_index(x, rw, m.w, x0, x1, wx0, wx1);
-    const float p00 = (m.low[y0 * m.w + x0] * m.mul_a) * m.mul_b;
-    const float p01 = (m.low[y0 * m.w + x1] * m.mul_a) * m.mul_b;
-    const float p10 = (m.low[y1 * m.w + x0] * m.mul_a) * m.mul_b;
-    const float p11 = (m.low[y1 * m.w + x1] * m.mul_a) * m.mul_b;
-    const float top = p00 * wx0 + p01 * wx1;
-    const float bot = p10 * wx0 + p11 * wx1;
-    float v = hy0 * top + hy1 * bot;
-    return v + pv;
+    const float rh = (float)h / (float)H, rw = (float)w / (float)W;
+    float hy0[N], hy1[N], wx0[N], wx1[N], t[N][4];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        int y0, y1, x0, x1;
+        src_index(ys[i], rh, h, y0, y1, hy0[i], hy1[i]);
+        src_index(xs[i], rw, w, x0, x1, wx0[i], wx1[i]);
+        t[i][0] = low[y0 * w + x0];
+        t[i][1] = low[y0 * w + x1];
+        t[i][2] = low[y1 * w + x0];
+        t[i][3] = low[y1 * w + x1];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float p00 = (t[i][0] * mul_a) * mul_b;
+        const float p01 = (t[i][1] * mul_a) * mul_b;
+        const float p10 = (t[i][2] * mul_a) * mul_b;
+        const float p11 = (t[i][3] * mul_a) * mul_b;
+        const float top = p00 * wx0[i] + p01 * wx1[i];
+        const float bot = p10 * wx0[i] + p11 * wx1[i];
+        out[i] = hy0[i] * top + hy1[i] * bot;
+    }
 }
 
-// N points of the same map at once: the operations of deferred_at per point, but every load of every point is issued before
-// the first use (four back-to-back deferred_at calls cost four dependent memory round trips: the early return keeps the
-// compiler from hoisting the later calls' loads -- 8.0k of the 10.4k cycles a k_volume_l1_warp workgroup lived, r03)
+// N points of the same map at once: the operations of k_upsample_add per point, but every load of every point is issued
+// before the first use (four back-to-back single-point evaluations cost four dependent memory round trips: 8.0k of the 10.4k
+// cycles a k_volume_l1_warp workgroup lived, r03).  prev_out (optional): the previous map's values at the points (what a
+// consumer writes out when that map is deferred too).
 template <int N>
 __device__ __forceinline__ void deferred_at_n(const DeferredMap &m, const int (&ys)[N], const int (&xs)[N], int H, int W,
-                                              float (&out)[N])
+                                              float (&out)[N], float *prev_out = nullptr)
 {
     float pv[N];
+    const bool have_prev = m.prev != nullptr || m.low0 != nullptr;      // (kernel-uniform)
+    if (m.prev != nullptr) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) pv[i] = m.prev[(int64_t)ys[i] * W + xs[i]];
+        for (int i = 0; i < N; ++i) pv[i] = m.prev[(int64_t)ys[i] * W + xs[i]];
+    } else if (m.low0 != nullptr) {
+        upsample_at_n<N>(m.low0, m.h0, m.w0, m.mul_a, m.mul_b0, ys, xs, H, W, pv);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) pv[i] = 0.0f;
+    }
+    if (prev_out != nullptr) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) prev_out[i] = pv[i];
+    }
     if (m.low == nullptr) {
 #pragma unroll
         for (int i = 0; i < N; ++i) out[i] = pv[i];
         return;
     }
-    const float rh = (float)m.h / (float)H, rw = (float)m.w / (float)W;
-    float hy0[N], hy1[N], wx0[N], wx1[N], t[N][4];
+    float v[N];
+    upsample_at_n<N>(m.low, m.h, m.w, m.mul_a, m.mul_b, ys, xs, H, W, v);
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        int y0, y1, x0, x1;
-        src_index(ys[i], rh, m.h, y0, y1, hy0[i], hy1[i]);
-        src_index(xs[i], rw, m.w, x0, x1, wx0[i], wx1[i]);
-        t[i][0] = m.low[y0 * m.w + x0];
-        t[i][1] = m.low[y0 * m.w + x1];
-        t[i][2] = m.low[y1 * m.w + x0];
-        t[i][3] = m.low[y1 * m.w + x1];
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const float p00 = (t[i][0] * m.mul_a) * m.mul_b;
-        const float p01 = (t[i][1] * m.mul_a) * m.mul_b;
-        const float p10 = (t[i][2] * m.mul_a) * m.mul_b;
-        const float p11 = (t[i][3] * m.mul_a) * m.mul_b;
-        const float top = p00 * wx0[i] + p01 * wx1[i];
-        const float bot = p10 * wx0[i] + p11 * wx1[i];
-        const float v = hy0[i] * top + hy1[i] * bot;
-        out[i] = v + pv[i];
-    }
+    for (int i = 0; i < N; ++i) out[i] = have_prev ? v[i] + pv[i] : v[i];
 }
 
 // sum_k softmax_k(-c) * (start + k) over D values c[k*stride]: max-subtracted, S summed ascending,

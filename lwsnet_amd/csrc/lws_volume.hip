@@ -161,12 +161,17 @@ __global__ __launch_bounds__(WARP_TX *WARP_NW) void k_volume_l1_warp(const float
                                                                       float *__restrict__ wflow_out, int h, int w,
                                                                       int H, int W, int m, float mul_a, float mul_b,
                                                                       const float *__restrict__ plow, int ph, int pw,
-                                                                      float *__restrict__ pmat, int force_gather)
+                                                                      float *__restrict__ pmat, int force_gather,
+                                                                      const float *__restrict__ plow0, int ph0, int pw0,
+                                                                      float *__restrict__ pmat0)
 {
     // plow != nullptr: the previous stage's full-resolution map has not been materialised (no k_upsample_add launch):
     // it is evaluated on demand as upsample(plow [ph,pw]) + prev (prev = the map of the stage before it), see
     // DeferredMap.  With H == 2h, W == 2w the four taps of pixel (y,x) are exactly the 2 x 2 block (2y..2y+1,
     // 2x..2x+1) of that map, so wave 0 also writes it out (pmat) -- the map is an output of the path.
+    // prev == nullptr (round 5): the map before it is not in memory either.  plow0 != nullptr: it is stage 1's map,
+    // upsample(plow0 [ph0,pw0]) with nothing added; this kernel evaluates it at the same four pixels and writes it to pmat0
+    // too.  plow0 == nullptr: there is no map before it (stage 2 reading stage 1's deferred map; nothing is written).
     constexpr int CP = C + 4;                                  // LDS floats per column: conflict-free 16-byte reads
     __shared__ float4 sR4[2 * WARP_NCMAX * CP / 4];            // [row][column][CP]
     __shared__ float sWf[WARP_TX];
@@ -200,17 +205,30 @@ __global__ __launch_bounds__(WARP_TX *WARP_NW) void k_volume_l1_warp(const float
             float hy0, hy1, wx0, wx1;
             src_index(y, rh_, H, y0, y1, hy0, hy1);
             src_index(x, rw_, W, x0, x1, wx0, wx1);
-            const DeferredMap dm{plow != nullptr ? plow + (int64_t)b * ph * pw : nullptr, prev + (int64_t)b * H * W, ph, pw,
-                                 (float)H, 1.0f / (float)(ph > 0 ? ph : 1)};
+            DeferredMap dm{plow != nullptr ? plow + (int64_t)b * ph * pw : nullptr,
+                           prev != nullptr ? prev + (int64_t)b * H * W : nullptr, ph, pw, (float)H, 1.0f / (float)(ph > 0 ? ph : 1)};
+            if (plow0 != nullptr) {
+                dm.low0 = plow0 + (int64_t)b * ph0 * pw0;
+                dm.h0 = ph0;
+                dm.w0 = pw0;
+                dm.mul_b0 = 1.0f / (float)(ph0 > 0 ? ph0 : 1);
+            }
             const int tys[4] = {y0, y0, y1, y1}, txs[4] = {x0, x1, x0, x1};
-            float q[4];
-            deferred_at_n<4>(dm, tys, txs, H, W, q);
+            float q[4], q0[4];
+            deferred_at_n<4>(dm, tys, txs, H, W, q, q0);
             if (pmat != nullptr) {
                 float *pm = pmat + (int64_t)b * H * W;
                 pm[(int64_t)y0 * W + x0] = q[0];
                 pm[(int64_t)y0 * W + x1] = q[1];
                 pm[(int64_t)y1 * W + x0] = q[2];
                 pm[(int64_t)y1 * W + x1] = q[3];
+            }
+            if (pmat0 != nullptr) {
+                float *pm = pmat0 + (int64_t)b * H * W;
+                pm[(int64_t)y0 * W + x0] = q0[0];
+                pm[(int64_t)y0 * W + x1] = q0[1];
+                pm[(int64_t)y1 * W + x0] = q0[2];
+                pm[(int64_t)y1 * W + x1] = q0[3];
             }
             const float top = q[0] * wx0 + q[1] * wx1;
             const float bot = q[2] * wx0 + q[3] * wx1;
@@ -358,10 +376,18 @@ __global__ __launch_bounds__(WARP_TX *WARP_NW) void k_volume_l1_warp(const float
 
 int launch_volume_l1_warp(const float *L, const float *R, const float *prev, float *cost, float *wflow_out,
                           int B, int C, int h, int w, int H, int W, int m, hipStream_t st, bool q16, const float *plow,
-                          int ph, int pw, float *pmat, int form)
+                          int ph, int pw, float *pmat, int form, const float *plow0, int ph0, int pw0, float *pmat0)
 {
-    if (pmat != nullptr && (plow == nullptr || H != 2 * h || W != 2 * w)) {
+    if ((pmat != nullptr || pmat0 != nullptr) && (plow == nullptr || H != 2 * h || W != 2 * w)) {
         set_error("volume_l1_warp: the deferred map can only be written out at exactly half resolution");
+        return LWS_ERR_INVALID;
+    }
+    if (prev == nullptr && plow == nullptr) {
+        set_error("volume_l1_warp: no previous map (neither materialised nor deferred)");
+        return LWS_ERR_INVALID;
+    }
+    if ((plow0 != nullptr && prev != nullptr) || (pmat0 != nullptr && plow0 == nullptr)) {
+        set_error("volume_l1_warp: the second deferred level stands in for a missing `prev`");
         return LWS_ERR_INVALID;
     }
     dim3 grid(cdiv(w, WARP_TX), h, B), block(WARP_TX * WARP_NW);
@@ -370,10 +396,10 @@ int launch_volume_l1_warp(const float *L, const float *R, const float *prev, flo
 #define LWS_VW(CC)                                                                                                   \
     if (q16)                                                                                                          \
         hipLaunchKernelGGL((k_volume_l1_warp<CC, true>), grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m,  \
-                           mul_a, mul_b, plow, ph, pw, pmat, force_gather);                                               \
+                           mul_a, mul_b, plow, ph, pw, pmat, force_gather, plow0, ph0, pw0, pmat0);                       \
     else                                                                                                              \
         hipLaunchKernelGGL((k_volume_l1_warp<CC, false>), grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m, \
-                           mul_a, mul_b, plow, ph, pw, pmat, force_gather)
+                           mul_a, mul_b, plow, ph, pw, pmat, force_gather, plow0, ph0, pw0, pmat0)
     switch (C) {
         case 8: LWS_VW(8); break;
         case 16: LWS_VW(16); break;
