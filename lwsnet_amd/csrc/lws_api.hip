@@ -588,7 +588,8 @@ struct DeferState {
 static bool refine_can_defer(const lws_ctx *h);
 
 static int refine_rest_chunk(lws_ctx *h, float *pred3, int B, int H, int W, const WsLayout &L, float *pred4, hipStream_t st,
-                             const DeferState *ds, const float *pred2, int b0, int scratch_b0 = 0, hipEvent_t after_disp = nullptr);
+                             const DeferState *ds, const float *pred2, int b0, int scratch_b0 = 0, hipEvent_t after_disp = nullptr,
+                             bool fuse_last = false);
 
 static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLayout &L, float *pred4,
                        hipStream_t st, const DeferState *ds = nullptr, const float *pred2 = nullptr)
@@ -599,6 +600,9 @@ static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLa
     // 64 -> 32 convolution; odd chunks use the second half of the (batch-sized) scratch maps.  Measured r03: 8 x 368x1232 (eight
     // chunks of one pair) 810 -> 833 pairs/s; 8 x 256x512 (two chunks of four) 2,958 -> 2,930: two chunks only add their
     // collisions, hence the automatic setting wants at least four.
+    // refinement2[4] + refinement2[5] + pred3 in one launch (k_ref_dws_last): option "fuse_ref_last"; automatic = batches <= 2,
+    // where a launch on the chain costs more than the ring's recomputation (measured round 5: profiles/NOTES.md)
+    const bool fuse_last = h->opt.fuse_ref_last >= 0 ? h->opt.fuse_ref_last != 0 : B <= 2;
     const int nchunks = (B + CH - 1) / CH;
     const int want = h->opt.ref_pipe >= 0 ? h->opt.ref_pipe : (nchunks >= 4 ? 1 : 0);
     const bool pipe = want != 0 && h->side != nullptr && h->opt.side_streams != 0 && nchunks >= 2 && 2 * CH <= B;
@@ -613,7 +617,7 @@ static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLa
         if (pipe && k > 0) LWS_HIP(hipStreamWaitEvent(cs, h->ev_feat[(k - 1) & 1], 0));
         const int rc = refine_rest_chunk(h, pred3 + po, std::min(CH, B - b0), H, W, L, pred4 + po, cs, ds,
                                          pred2 != nullptr ? pred2 + po : nullptr, b0, pipe ? (k & 1) * CH : 0,
-                                         pipe ? h->ev_feat[k & 1] : nullptr);
+                                         pipe ? h->ev_feat[k & 1] : nullptr, fuse_last);
         if (rc) return rc;
     }
     if (pipe) {
@@ -624,7 +628,7 @@ static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLa
 }
 
 static int refine_rest_chunk(lws_ctx *h, float *pred3, int B, int H, int W, const WsLayout &L, float *pred4, hipStream_t st,
-                             const DeferState *ds, const float *pred2, int b0, int scratch_b0, hipEvent_t after_disp)
+                             const DeferState *ds, const float *pred2, int b0, int scratch_b0, hipEvent_t after_disp, bool fuse_last)
 {
     const Net2d &n = h->net2d;
     // r_a: this chunk's slice (refinement1_left's result); r_b, r_c: the same memory for every chunk
@@ -653,6 +657,11 @@ static int refine_rest_chunk(lws_ctx *h, float *pred3, int B, int H, int W, cons
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[0], rc_, ra, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[1], ra, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[2], rc_, ra, B, H, W, st));
+    // refinement2[4] + refinement2[5] + pred3: one launch (k_ref_dws_last) or two (refine_rest decides)
+    if (fuse_last && ref_dws_last_can_fuse(n.r2[3])) {
+        LWS_RF(LWS_KC_REF_LAST, launch_ref_dws_last(n.r2[3], ra, n.r2_last, pred3, pred4, B, H, W, st));
+        return LWS_OK;
+    }
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r2[3], ra, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_LAST, launch_ref_last(rc_, n.r2_last, pred3, pred4, B, H, W, st));
     return LWS_OK;
@@ -927,6 +936,7 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"mid8_balance", &h->opt.mid8_balance},
                                                      {"side_xcds", &h->opt.side_xcds},
                                                      {"fuse_last1", &h->opt.fuse_last1},
+                                                     {"fuse_ref_last", &h->opt.fuse_ref_last},
                                                      {"device", &h->device},
                                                      {"mid8_form", &h->opt.mid8_form}};
     for (auto &e : tab)
@@ -950,7 +960,7 @@ int lws_set_option(lws_handle h, const char *name, int value)
     LWS_CHECK_ARG(slot != nullptr, "lws_set_option: unknown option '%s'", name);
     if (strcmp(name, "left_at") == 0)
         LWS_CHECK_ARG(value == -1 || value == 0 || value == 2, "lws_set_option: left_at must be -1 (auto), 0 or 2 (got %d)", value);
-    else if (strcmp(name, "split_heads") == 0 || strcmp(name, "ref_pipe") == 0)
+    else if (strcmp(name, "split_heads") == 0 || strcmp(name, "ref_pipe") == 0 || strcmp(name, "fuse_ref_last") == 0)
         LWS_CHECK_ARG(value >= -1 && value <= 1, "lws_set_option: %s must be -1 (auto), 0 or 1 (got %d)", name, value);
     else if (strcmp(name, "ref_chunk_mb") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 4096, "lws_set_option: ref_chunk_mb must be in 0..4096 (got %d)", value);

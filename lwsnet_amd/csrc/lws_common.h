@@ -185,6 +185,7 @@ struct lws_ctx {
         int mid8_balance = 1;      // k_conv3d_mid8q: small grids take small tiles with the residency capped so that every CU gets the same number
         int warp_form = 1;         // residual volumes: 1 = right-feature window of a 64-pixel row segment staged in LDS, 0 = every tap gathered from global memory
         int fuse_last1 = 1;        // batches <= 2: stage 1's last Conv3D layer + soft-argmin in one launch, pred1 evaluated by its consumers
+        int fuse_ref_last = -1;    // refinement2's last block + the 32 -> 1 convolution + pred3 in one launch: -1 = by batch, 0 / 1
         int side_xcds = 0;         // 1..7: the side stream is confined to the CUs of that many XCDs (CU-masked stream); 0 = unmasked
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
     } opt;
@@ -261,6 +262,9 @@ int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst,
 int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, float *out, int B, int H, int W,
                       hipStream_t st);
 int launch_ref_last(const float *in, const float *w, const float *pred3, float *out, int B, int H, int W, hipStream_t st);
+bool ref_dws_last_can_fuse(const RefDws &l);
+int launch_ref_dws_last(const RefDws &l, const float *in, const float *wlast, const float *pred3, float *out, int B, int H, int W,
+                        hipStream_t st);
 void pack_conv2d_mfma(const float *w, int cin, int ktaps, float *out);
 size_t packed_conv64x_floats();
 void pack_conv64_bf16x3(const float *w, float *out);   // [32][64][3][3] -> k_ref_conv64x fragments

@@ -255,18 +255,22 @@ def test_refine_chunks_over_two_streams(dev, model):
 
 @pytest.mark.parametrize("B,H,W", [(1, 64, 256), (2, 40, 72), (1, 136, 152), (1, 63, 255), (3, 33, 47)])
 @pytest.mark.parametrize("chunk_mb", [72, 1])
-def test_refine_bitexact(dev, model, B, H, W, chunk_mb):
-    """chunk_mb = 1: the refinement runs one pair per chunk (option ref_chunk_mb; pairs are independent, so the same bits)."""
+@pytest.mark.parametrize("fuse_last", [0, 1])
+def test_refine_bitexact(dev, model, B, H, W, chunk_mb, fuse_last):
+    """chunk_mb = 1: the refinement runs one pair per chunk (option ref_chunk_mb; pairs are independent, so the same bits).
+    fuse_last: refinement2's last block + the 32 -> 1 convolution + pred3 as one launch (k_ref_dws_last, round 5) or as two."""
     from lwsnet_amd import ops
     from oracle import c_oracle as C
     rng = np.random.default_rng(9)
     left = rng.standard_normal((B, 3, H, W)).astype(np.float32)
     pred3 = (rng.random((B, 1, H, W)) * 150.0).astype(np.float32)
     model.set_option("ref_chunk_mb", chunk_mb)
+    model.set_option("fuse_ref_last", fuse_last)
     try:
         got = ops.refine(model._h, cu(left, dev), cu(pred3, dev))
     finally:
         model.set_option("ref_chunk_mb", 72)
+        model.set_option("fuse_ref_last", -1)
     assert_bits(got, C.refine(left, pred3, model.state_dict()), "refine")
 
 
@@ -282,8 +286,14 @@ def test_refine_ragged_sweep(dev, model):
     for B, H, W in sizes:
         left = rng.standard_normal((B, 3, H, W)).astype(np.float32)
         pred3 = (rng.random((B, 1, H, W)) * 150.0).astype(np.float32)
-        got = ops.refine(model._h, cu(left, dev), cu(pred3, dev))
-        assert_bits(got, C.refine(left, pred3, model.state_dict()), f"refine {B}x{H}x{W}")
+        want = C.refine(left, pred3, model.state_dict())
+        for fuse_last in (0, 1):                        # k_ref_dws + k_ref_last, and k_ref_dws_last
+            model.set_option("fuse_ref_last", fuse_last)
+            try:
+                got = ops.refine(model._h, cu(left, dev), cu(pred3, dev))
+            finally:
+                model.set_option("fuse_ref_last", -1)
+            assert_bits(got, want, f"refine {B}x{H}x{W} fuse_ref_last={fuse_last}")
 
 
 def test_forward_bitexact_vs_c_oracle(dev, model):
@@ -358,6 +368,7 @@ OPTION_PLANS = [{"left_at": 0}, {"left_at": 2}, {"split_heads": 1}, {"split_head
                 {"side_streams": 0}, {"side_streams": 0, "left_at": 0}, {"left_at": 2, "split_heads": 1},
                 {"warp_form": 0}, {"warp_form": 0, "defer_upsample": 0}, {"mid8_balance": 0},
                 {"side_xcds": 2}, {"side_xcds": 6, "left_at": 0}, {"fuse_last1": 0}, {"fuse_last1": 1, "warp_form": 0},
+                {"fuse_ref_last": 0}, {"fuse_ref_last": 1},
                 {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0, "mid8_form": 1}]
 
 
