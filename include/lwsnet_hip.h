@@ -176,12 +176,13 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *                    one launch (24 x 2 x 4 tiles spanning D) and NO launch materialises pred1: stage 2's warp kernel evaluates
  *                    the taps it needs from the 1/8 map, stage 3's warp kernel writes pred1 beside pred2 (round 5: one launch
  *                    less on the batch-1 chain); 0 = k_conv3d_last + k_softargmin_upsample
- *   "fuse_ref_last"  -1 (default: batches <= 2) / 0 / 1: refinement2's last depthwise-separable block (dilation 1), the 32 -> 1
+ *   "fuse_ref_last"  -1 (default: batch 1 only) / 0 / 1: refinement2's last depthwise-separable block (dilation 1), the 32 -> 1
  *                    convolution and "+ pred3" in one launch (k_ref_dws_last: the block recomputed on the one-pixel ring the
  *                    convolution needs; round 5) instead of k_ref_dws + k_ref_last
- *   "side_xcds"      0 (default) / 1..7: the handle's side stream (feature-extractor tail, refinement1_left, alternate
- *                    refinement chunks) is a CU-masked stream confined to that many of the 8 XCDs (the last n), so that its
- *                    HBM-bound kernels do not share CUs with the caller's stream's MFMA kernels on the other XCDs (round 5)
+ *   "side_cus"       0 (default) / 1..31: the handle's side stream (feature-extractor tail, refinement1_left, alternate
+ *                    refinement chunks) is a CU-masked stream limited to that many compute units of EVERY XCD (whole-XCD
+ *                    confinement does not exist on this part: tools/micro/cumask.hip), so that its HBM-bound kernels share
+ *                    only those CUs with the caller's stream's MFMA kernels (round 5)
  *   "device"         the HIP device the handle belongs to; settable only before lws_finalize / lws_reserve allocate
  * Unknown names and out-of-range values return LWS_ERR_INVALID. */
 int lws_set_option(lws_handle h, const char *name, int value);

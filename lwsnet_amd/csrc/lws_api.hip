@@ -600,9 +600,11 @@ static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLa
     // 64 -> 32 convolution; odd chunks use the second half of the (batch-sized) scratch maps.  Measured r03: 8 x 368x1232 (eight
     // chunks of one pair) 810 -> 833 pairs/s; 8 x 256x512 (two chunks of four) 2,958 -> 2,930: two chunks only add their
     // collisions, hence the automatic setting wants at least four.
-    // refinement2[4] + refinement2[5] + pred3 in one launch (k_ref_dws_last): option "fuse_ref_last"; automatic = batches <= 2,
-    // where a launch on the chain costs more than the ring's recomputation (measured round 5: profiles/NOTES.md)
-    const bool fuse_last = h->opt.fuse_ref_last >= 0 ? h->opt.fuse_ref_last != 0 : B <= 2;
+    // refinement2[4] + refinement2[5] + pred3 in one launch (k_ref_dws_last): option "fuse_ref_last"; automatic = batch 1 only
+    // (measured round 5, pairs/s fused vs two launches: 2,061-2,076 vs 2,047-2,071 at batch 1, 2,569 vs 2,581 at batch 2, 2,988 vs
+    // 3,013 at batch 8, 837 vs 840 at 8 x 368x1232 -- the fused launch takes as long as the two it replaces, 19.3 vs 10.9 + 8.6 us,
+    // so all it buys is one dispatch gap: profiles/r05/experiments/ab_fuse_ref_last.txt)
+    const bool fuse_last = h->opt.fuse_ref_last >= 0 ? h->opt.fuse_ref_last != 0 : B <= 1;
     const int nchunks = (B + CH - 1) / CH;
     const int want = h->opt.ref_pipe >= 0 ? h->opt.ref_pipe : (nchunks >= 4 ? 1 : 0);
     const bool pipe = want != 0 && h->side != nullptr && h->opt.side_streams != 0 && nchunks >= 2 && 2 * CH <= B;
@@ -830,20 +832,22 @@ static int check_device(const lws_ctx *h, const char *what)
 
 // side streams and cross-stream events of lws_forward: created by lws_reserve (which promises that later calls allocate
 // nothing) or, for callers that never reserve, on the first forward
-// Option "side_xcds" = n in 1..7: the side stream may only use the CUs of n of the 8 XCDs (hipExtStreamCreateWithCUMask).  The
-// mask's bit i is CU slot i / 8 of XCD i % 8 on this part (tools/micro/cumask.hip prints the map), so whole XCDs are the bits
-// with i % 8 >= 8 - n.  0 = no mask (the default).
+// Option "side_cus" = k in 1..31: the side stream may only use k compute units of EVERY XCD (hipExtStreamCreateWithCUMask).
+// Measured round 5 (tools/micro/cumask.hip, profiles/r05/micro_cumask.txt): bit i of the mask is CU slot i / 8 of XCD i % 8, so
+// the low 8 k bits are k CUs in each of the 8 XCDs.  A mask that leaves an XCD WITHOUT a CU is unusable: in this partition mode
+// the dispatcher hands workgroups to all 8 XCDs round-robin whatever the mask says (a stream masked to whole XCDs ran 2x slower
+// at batch 1 whatever the count, and one pattern hung the micro-benchmark), so whole-XCD confinement -- what VERDICT r4 asked to
+// try -- does not exist on this part; a per-XCD CU budget does.  0 = no mask (the default).
 static int create_side_stream(lws_ctx *h, hipStream_t *out)
 {
-    const int n = h->opt.side_xcds;
-    if (n <= 0 || n >= 8) {
+    const int k = h->opt.side_cus;
+    const int ncu = h->cu_count > 0 ? h->cu_count : 256;
+    if (k <= 0 || 8 * k >= ncu) {
         LWS_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
         return LWS_OK;
     }
-    const int ncu = h->cu_count > 0 ? h->cu_count : 256;
     std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-    for (int i = 0; i < ncu; ++i)
-        if (i % 8 >= 8 - n) mask[(size_t)i / 32] |= 1u << (i % 32);
+    for (int i = 0; i < 8 * k; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
     LWS_HIP(hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()));
     return LWS_OK;
 }
@@ -934,7 +938,7 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"ref_pipe", &h->opt.ref_pipe},
                                                      {"warp_form", &h->opt.warp_form},
                                                      {"mid8_balance", &h->opt.mid8_balance},
-                                                     {"side_xcds", &h->opt.side_xcds},
+                                                     {"side_cus", &h->opt.side_cus},
                                                      {"fuse_last1", &h->opt.fuse_last1},
                                                      {"fuse_ref_last", &h->opt.fuse_ref_last},
                                                      {"device", &h->device},
@@ -972,15 +976,15 @@ int lws_set_option(lws_handle h, const char *name, int value)
     }
     else if (strcmp(name, "mid8_form") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 2, "lws_set_option: mid8_form must be 0, 1 or 2 (got %d)", value);
-    else if (strcmp(name, "side_xcds") == 0) {
-        LWS_CHECK_ARG(value >= 0 && value <= 7, "lws_set_option: side_xcds must be in 0..7 (got %d)", value);
-        if (h->side != nullptr && value != h->opt.side_xcds) {
+    else if (strcmp(name, "side_cus") == 0) {
+        LWS_CHECK_ARG(value >= 0 && value <= 31, "lws_set_option: side_cus must be in 0..31 (got %d)", value);
+        if (h->side != nullptr && value != h->opt.side_cus) {
             // the mask is a property of the stream: replace the side stream (nothing of this handle may be in flight)
-            LWS_CHECK_DEVICE(h, "lws_set_option(side_xcds)");
+            LWS_CHECK_DEVICE(h, "lws_set_option(side_cus)");
             LWS_HIP(hipStreamSynchronize(h->side));
             LWS_HIP(hipStreamDestroy(h->side));
             h->side = nullptr;
-            h->opt.side_xcds = value;
+            h->opt.side_cus = value;
             const int rc = create_side_stream(h, &h->side);
             if (rc) return rc;
         }
