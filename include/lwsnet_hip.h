@@ -179,10 +179,6 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "fuse_ref_last"  -1 (default: batch 1 only) / 0 / 1: refinement2's last depthwise-separable block (dilation 1), the 32 -> 1
  *                    convolution and "+ pred3" in one launch (k_ref_dws_last: the block recomputed on the one-pixel ring the
  *                    convolution needs; round 5) instead of k_ref_dws + k_ref_last
- *   "side_cus"       0 (default) / 1..31: the handle's side stream (feature-extractor tail, refinement1_left, alternate
- *                    refinement chunks) is a CU-masked stream limited to that many compute units of EVERY XCD (whole-XCD
- *                    confinement does not exist on this part: tools/micro/cumask.hip), so that its HBM-bound kernels share
- *                    only those CUs with the caller's stream's MFMA kernels (round 5)
  *   "device"         the HIP device the handle belongs to; settable only before lws_finalize / lws_reserve allocate
  * Unknown names and out-of-range values return LWS_ERR_INVALID. */
 int lws_set_option(lws_handle h, const char *name, int value);

@@ -832,34 +832,19 @@ static int check_device(const lws_ctx *h, const char *what)
 
 // side streams and cross-stream events of lws_forward: created by lws_reserve (which promises that later calls allocate
 // nothing) or, for callers that never reserve, on the first forward
-// Option "side_cus" = k in 1..31: the side stream may only use k compute units of EVERY XCD (hipExtStreamCreateWithCUMask).
-// Measured round 5 (tools/micro/cumask.hip, profiles/r05/micro_cumask.txt): bit i of the mask is CU slot i / 8 of XCD i % 8, so
-// the low 8 k bits are k CUs in each of the 8 XCDs.  A mask that leaves an XCD WITHOUT a CU is unusable: in this partition mode
-// the dispatcher hands workgroups to all 8 XCDs round-robin whatever the mask says (a stream masked to whole XCDs ran 2x slower
-// at batch 1 whatever the count, and one pattern hung the micro-benchmark), so whole-XCD confinement -- what VERDICT r4 asked to
-// try -- does not exist on this part; a per-XCD CU budget does.  0 = no mask (the default).
-static int create_side_stream(lws_ctx *h, hipStream_t *out)
-{
-    const int k = h->opt.side_cus;
-    const int ncu = h->cu_count > 0 ? h->cu_count : 256;
-    if (k <= 0 || 8 * k >= ncu) {
-        LWS_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
-        return LWS_OK;
-    }
-    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-    for (int i = 0; i < 8 * k; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-    LWS_HIP(hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()));
-    return LWS_OK;
-}
-
+// (Round 5, built, measured, removed: a CU-masked side stream, hipExtStreamCreateWithCUMask -- VERDICT r4 item 2b.  Whole-XCD
+// masks do not exist on this part: bit i of the mask is CU slot i / 8 of XCD i % 8, the dispatcher hands workgroups to all 8
+// XCDs whatever the mask says, and a mask that leaves an XCD empty ran as if unmasked or hung (tools/micro/cumask.hip).  A
+// per-XCD CU budget (the low 8 k bits) works as a mask but not as a plan: with ANY masked stream in the process every kernel
+// of the forward slowed down, also those on the unmasked stream -- 8 x 256x512: 2,989 pairs/s unmasked, 1,407 / 1,881 / 2,094 /
+// 2,226 / 2,363 with 4 / 8 / 12 / 16 / 24 CUs per XCD; batch 1: 2,060 -> 922-993; 8 x 368x1232: 831 -> 421-708 -- and a plain
+// copy kernel on a 64-CU mask hung until its timeout.  profiles/r05/experiments/sweep_side_cus_per_xcd_budget.txt,
+// sweep_side_xcds_whole_xcd_masks.txt, profiles/r05/micro_cumask.txt.)
 static int ensure_streams(lws_ctx *h)
 {
     if (h->side) return LWS_OK;
     const unsigned ef = hipEventDisableTiming | hipEventDisableSystemFence;
-    {
-        const int rc = create_side_stream(h, &h->side);
-        if (rc) return rc;
-    }
+    LWS_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     LWS_HIP(hipEventCreateWithFlags(&h->ev_fork, ef));
     LWS_HIP(hipEventCreateWithFlags(&h->ev_join, ef));
     for (int i = 0; i < 3; ++i) LWS_HIP(hipEventCreateWithFlags(&h->ev_feat[i], ef));
@@ -938,7 +923,6 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"ref_pipe", &h->opt.ref_pipe},
                                                      {"warp_form", &h->opt.warp_form},
                                                      {"mid8_balance", &h->opt.mid8_balance},
-                                                     {"side_cus", &h->opt.side_cus},
                                                      {"fuse_last1", &h->opt.fuse_last1},
                                                      {"fuse_ref_last", &h->opt.fuse_ref_last},
                                                      {"device", &h->device},
@@ -976,19 +960,6 @@ int lws_set_option(lws_handle h, const char *name, int value)
     }
     else if (strcmp(name, "mid8_form") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 2, "lws_set_option: mid8_form must be 0, 1 or 2 (got %d)", value);
-    else if (strcmp(name, "side_cus") == 0) {
-        LWS_CHECK_ARG(value >= 0 && value <= 31, "lws_set_option: side_cus must be in 0..31 (got %d)", value);
-        if (h->side != nullptr && value != h->opt.side_cus) {
-            // the mask is a property of the stream: replace the side stream (nothing of this handle may be in flight)
-            LWS_CHECK_DEVICE(h, "lws_set_option(side_cus)");
-            LWS_HIP(hipStreamSynchronize(h->side));
-            LWS_HIP(hipStreamDestroy(h->side));
-            h->side = nullptr;
-            h->opt.side_cus = value;
-            const int rc = create_side_stream(h, &h->side);
-            if (rc) return rc;
-        }
-    }
     else
         LWS_CHECK_ARG(value == 0 || value == 1, "lws_set_option: %s must be 0 or 1 (got %d)", name, value);
     *slot = value;

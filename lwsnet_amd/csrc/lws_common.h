@@ -186,7 +186,6 @@ struct lws_ctx {
         int warp_form = 1;         // residual volumes: 1 = right-feature window of a 64-pixel row segment staged in LDS, 0 = every tap gathered from global memory
         int fuse_last1 = 1;        // batches <= 2: stage 1's last Conv3D layer + soft-argmin in one launch, pred1 evaluated by its consumers
         int fuse_ref_last = -1;    // refinement2's last block + the 32 -> 1 convolution + pred3 in one launch: -1 = batch 1 only, 0 / 1
-        int side_cus = 0;          // 1..31: the side stream is a CU-masked stream limited to that many CUs of every XCD; 0 = unmasked
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
     } opt;
     unsigned prof_mask = 0;                  // kernel classes being timed in the current call
