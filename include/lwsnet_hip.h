@@ -168,6 +168,9 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "mid8_balance"   1 (default) / 0: on grids of at most four small (3 x 4 x 32) tiles per CU, k_conv3d_mid8q takes the small
  *                    tile and asks for 160 KB / k of LDS so that exactly k workgroups are resident per CU (one 256x512 pair at
  *                    stage 3: 768 tiles = 3 per CU instead of 384 large tiles = 2 on half of the CUs); lws_pool workers run with 0
+ *   "mid8_tile"      0 (default: by grid size -- 3 x 8 x 32 voxels once >= 192 such tiles exist and they balance, else 3 x 2 x 32,
+ *                    round 5) / 1..4 force k_conv3d_mid8q's tile: 3x2, 1x4, 3x4 (with "mid8_balance"'s residency cap), 3x8
+ *                    rows x 32; t2 + 8 t3 addresses stages 2 and 3 separately
  *   "warp_form"      residual volumes of stages 2 and 3: 1 (default) = k_volume_l1_warp stages the right-feature window of a
  *                    64-pixel row segment (all channels, zero-filled outside the image) in LDS and computes the 2m - 1
  *                    hypotheses from it; 0 = every tap gathered from global memory (the form a tile falls back to when its

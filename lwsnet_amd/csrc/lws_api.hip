@@ -903,6 +903,8 @@ static void apply_options(lws_ctx *h)
         h->stage[i].dfast = h->opt.conv3d_order;
         h->stage[i].mid16_form = h->opt.mid16_form;
         h->stage[i].mid8_balance = h->opt.mid8_balance;
+        // (experiment knob: values >= 8 address the stages separately -- stage 2 takes v % 8, stage 3 v / 8)
+        h->stage[i].mid8_tile = h->opt.mid8_tile < 8 ? h->opt.mid8_tile : (i == 2 ? h->opt.mid8_tile / 8 : h->opt.mid8_tile % 8);
         h->stage[i].cu_count = h->cu_count;
     }
     h->net2d.r2_first.form = h->opt.conv64_form;
@@ -924,6 +926,7 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"warp_form", &h->opt.warp_form},
                                                      {"mid8_balance", &h->opt.mid8_balance},
                                                      {"fuse_last1", &h->opt.fuse_last1},
+                                                     {"mid8_tile", &h->opt.mid8_tile},
                                                      {"fuse_ref_last", &h->opt.fuse_ref_last},
                                                      {"device", &h->device},
                                                      {"mid8_form", &h->opt.mid8_form}};
@@ -960,6 +963,8 @@ int lws_set_option(lws_handle h, const char *name, int value)
     }
     else if (strcmp(name, "mid8_form") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 2, "lws_set_option: mid8_form must be 0, 1 or 2 (got %d)", value);
+    else if (strcmp(name, "mid8_tile") == 0)
+        LWS_CHECK_ARG(value >= 0 && value <= 39 && value % 8 <= 4, "lws_set_option: mid8_tile must be t or t2 + 8 * t3 with t in 0..4 (got %d)", value);
     else
         LWS_CHECK_ARG(value == 0 || value == 1, "lws_set_option: %s must be 0 or 1 (got %d)", name, value);
     *slot = value;

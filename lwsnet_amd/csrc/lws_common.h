@@ -119,6 +119,7 @@ struct Stage3d {
     int c3 = 0;
     int mid8_form = 1;                 // 8 -> 8 layers: 0 = k_conv3d_mid8 (16x16x4, parity rows), 1 = k_conv3d_mid8q (4x4x1_16B)
     int mid16_form = 0;                // 32 -> 32 layers: 0 = k_conv3d_mid16 (f32 MFMA, the oracle's chain), 1 = k_conv3d_mid16x (split-bf16, not bit-exact)
+    int mid8_tile = 0;                 // 0 = automatic (3x8 or 3x2 rows x 32 by grid size), 1..4 force k_conv3d_mid8q's tile (3x2, 1x4, 3x4, 3x8)
     int mid8_balance = 1;              // k_conv3d_mid8q on small grids: small tiles with the per-CU residency capped (even spread over the CUs)
     int cu_count = 0;                  // compute units of the handle's device (0 = unknown: 256)
     int dfast = 1;                     // tile order of the stack's kernels: 0 = x, y, d; 1 = d fastest (tile_coords, lws_conv3d.hip)
@@ -185,6 +186,7 @@ struct lws_ctx {
         int mid8_balance = 1;      // k_conv3d_mid8q: small grids take small tiles with the residency capped so that every CU gets the same number
         int warp_form = 1;         // residual volumes: 1 = right-feature window of a 64-pixel row segment staged in LDS, 0 = every tap gathered from global memory
         int fuse_last1 = 1;        // batches <= 2: stage 1's last Conv3D layer + soft-argmin in one launch, pred1 evaluated by its consumers
+        int mid8_tile = 0;         // force k_conv3d_mid8q's tile shape (see Stage3d); 0 = automatic
         int fuse_ref_last = -1;    // refinement2's last block + the 32 -> 1 convolution + pred3 in one launch: -1 = batch 1 only, 0 / 1
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
     } opt;

@@ -1658,8 +1658,21 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
                 // (Round 4, built, bit-exact, measured, removed: the same tiles on packed float32 VALU -- v_pk_fma_f32 with the
                 // weights as SGPR pairs, priced at 119-122 TF by tools/micro/pkfma_conv.hip -- ran at 76 TF in place against this
                 // kernel's 100 at 8 x 9x128x256, 43 vs 61 at B = 1: profiles/r04/experiments/sbench_mid8v_packed_valu_form.txt.)
+                // Round 5 ("more, smaller workgroups for the launch-bound layers"): wherever the rule above
+                // picks the small tile, 3 x 2 x 32 voxels (3 waves, 21.8 KB, halo 3.5x, no residency cap) replace 3 x 4 x 32.
+                // Alone the two are equal (tools/sbench.py, one pair: stage 2 8.2 vs 7.8 us, stage 3 16.3 vs 16.6); in the forward,
+                // where these launches run beside refinement1_left's k_ref_dws on the side stream, the smaller workgroups
+                // co-schedule better: 2,088-2,094 vs 2,065-2,070 pairs/s at batch 1 (+1.0 %), both stages contributing (stage 3
+                // only: 2,080).  Forced on grids where the LARGE tile is the automatic choice it loses: 2,555 vs 2,587 at batch 2,
+                // 2,970 vs 3,009 at batch 8, 613 vs 627 at 544x960; 1 x 4 x 32 tiles (2 waves) lose everywhere (2,022-2,026).
+                // profiles/r05/experiments/bench_mid8_tile*.txt, sbench_mid8_tile_b1.txt.  Option "mid8_tile" forces a shape
+                // (1 = 3x2, 2 = 1x4, 3 = 3x4 with round 4's residency cap, 4 = 3x8; t2 + 8 t3 addresses the stages separately).
+                if (s.mid8_tile == 1) return mid8q_launch<3, 2>(s, layer, act_in, act_out, B, D, h, w, st);
+                if (s.mid8_tile == 2) return mid8q_launch<1, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+                if (s.mid8_tile == 3) return mid8q_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st, cap);
+                if (s.mid8_tile == 4) return mid8q_launch<3, 8>(s, layer, act_in, act_out, B, D, h, w, st);
                 if (big_tiles >= 192 && !small_wins) return mid8q_launch<3, 8>(s, layer, act_in, act_out, B, D, h, w, st);
-                return mid8q_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st, cap);
+                return mid8q_launch<3, 2>(s, layer, act_in, act_out, B, D, h, w, st);
             }
             return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
         }
