@@ -558,7 +558,10 @@ def main():
     hw_s = [(h2 // 4) * (w2 // 4), (h2 // 2) * (w2 // 2), h2 * w2]
     first_bytes = sum(((2 * 16 * hw_s[0] + vox_s[0]) if si == 0 else vox_s[si]) + c3_s[si] * vox_s[si] for si in range(3)) * 4.0 * B
     last_bytes = sum((c3_s[si] + 1) * vox_s[si] + (vox_s[si] if si == 0 else hw_s[si]) for si in range(3)) * 4.0 * B
-    for name, step_bytes in (("volume_l1_warp", float(sum(warp_bytes))), ("ref_dws", 12 * 2.0 * B * H * W * 32 * 4),
+    # (refinement2's last block runs inside k_ref_dws_last -- class ref_last -- at batch 1: option "fuse_ref_last")
+    frl = model.get_option("fuse_ref_last")
+    dws_blocks = 11 if (frl == 1 or (frl == -1 and B <= 1)) else 12
+    for name, step_bytes in (("volume_l1_warp", float(sum(warp_bytes))), ("ref_dws", dws_blocks * 2.0 * B * H * W * 32 * 4),
                              ("softargmin", (margs.maxdisplist[0] * (h2 // 4) * (w2 // 4) + H * W) * 4.0 * B),
                              ("conv3d_first", first_bytes), ("conv3d_last", last_bytes)):
         if name in kernels:

@@ -1097,7 +1097,11 @@ def test_profiler_counts_and_sampling(dev, model, hip_lib):
     got = dict(zip(names, list(cnt)))
     assert got["conv3d_mid16"] == 4 and got["conv3d_mid8"] == 8 and got["conv3d_first"] == 3 and got["conv3d_last"] == 3
     # (the stage-1 volume is built inside the first Conv3D launch unless lws_set_option("fuse_shift", 0))
-    assert got["volume_l1_shift"] in (0, 1) and got["volume_l1_warp"] == 2 and got["ref_conv64"] == 1 and got["ref_dws"] == 12
+    # (batch 1: refinement2's last block runs inside k_ref_dws_last, class ref_last, unless lws_set_option("fuse_ref_last", 0);
+    # stage 1's soft-argmin inside its last Conv3D layer, and no k_upsample_add launch, unless "fuse_last1" / "defer_upsample" = 0)
+    assert got["volume_l1_shift"] in (0, 1) and got["volume_l1_warp"] == 2 and got["ref_conv64"] == 1 and got["ref_dws"] == 11
+    assert got["ref_last"] == 1 and got["softargmin"] == 0 and got["upsample_add"] == 0 and got["feature_conv2d"] == 8
+    assert sum(cnt) == 4 + 8 + 3 + 3 + 2 + 1 + 11 + 1 + 8 + 1        # 42 launches per batch-1 forward (33 on the caller's stream)
     assert all(t >= 0.0 for t in tot) and tot[names.index("conv3d_mid16")] > 0.0
     # sampling: 6 calls, every 3rd recorded -> 2 forwards' worth of mid16 launches
     _lib.check(hip_lib.lws_profile_enable(model._h, 1 << names.index("conv3d_mid16")))

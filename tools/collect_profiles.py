@@ -3,7 +3,7 @@
 lines.  It only ever writes the files it copies: whatever else lives in the destination (experiments, notes, evidence of other
 runs) stays -- round 3's version deleted every file it had not produced, which is how cited evidence went missing.
 
-    python tools/collect_profiles.py [gpurun_out/final] [profiles/r04]"""
+    python tools/collect_profiles.py [gpurun_out/final] [profiles/r05]"""
 import csv
 import json
 import os
@@ -11,9 +11,9 @@ import shutil
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r04"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r05"
 os.makedirs(dst, exist_ok=True)
-PREFIXES = ("bench_", "sbench_", "rbench_", "wbench", "pool_bench_", "micro_", "stamps_", "kernel_stats_", "pmc_", "timeline_", "gather_")
+PREFIXES = ("bench_", "sbench_", "rbench_", "wbench", "pool_bench_", "micro_", "stamps_", "kernel_stats_", "pmc_", "timeline_", "gather_", "overlap_account_")
 copied = []
 for n in sorted(os.listdir(src)):
     p = os.path.join(src, n)

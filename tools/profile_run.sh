@@ -1,7 +1,7 @@
 #!/bin/bash
 # Produces everything profiles/rNN is built from, on the GPU box, under gpurun_out/final (summaries only: the raw rocprofv3
 # CSVs are condensed on the box by tools/pmc_summary.py / tools/timeline.py and deleted -- gpurun merges back <= 64 MiB):
-#   gpurun --timeout 2400 -- 'bash tools/profile_run.sh'      then here:  python tools/collect_profiles.py gpurun_out/final profiles/r04
+#   gpurun --timeout 2400 -- 'bash tools/profile_run.sh'      then here:  python tools/collect_profiles.py gpurun_out/final profiles/r05
 # Counter passes (--pmc) are separate rocprofv3 runs without any trace domain; the program after `--` is python3 itself.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
@@ -13,6 +13,8 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_b1_driver_flags.json"
 python bench.py --batch 8 --no-cpu-baseline --no-pipelined --steps 30 > "$O/bench_b8.json" 2> /dev/null
 python bench.py --batch 8 --size 368x1232 --no-cpu-baseline --no-pipelined --steps 10 --warmup 3 > "$O/bench_cfg3.json" 2> /dev/null
 python bench.py --size 544x960 --maxdisp0 32 --feature-fp16 --no-cpu-baseline --no-pipelined --steps 20 > "$O/bench_cfg5.json" 2> /dev/null
+# the N-rank code path with two processes on this one GPU (gloo; value is null: the ranks share the chip)
+python bench.py --gpus 2 --one-gpu --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$O/bench_two_ranks_one_gpu_b8.json" 2> /dev/null
 for i in 1 2 3 4 5 6 7 8; do
   python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pipelined 2>/dev/null | python -c "
 import json,sys
@@ -27,11 +29,18 @@ cd /tmp; export TMPDIR=/tmp
 # kernel statistics + the timeline of one B=1 forward (back = 50 latency + 10 breakdown forwards behind the timed region + 30)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o run -- python3 "$R/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-pipelined > "$O/bench_under_rocprof.json" 2> "$O/kt.err"
 python3 "$R/tools/timeline.py" "$O/kt/run_kernel_trace.csv" 90 > "$O/timeline_b1.txt" 2>&1
+python3 "$R/tools/overlap_account.py" "$O/kt/run_kernel_trace.csv" 90 8 > "$O/overlap_account_b1_256x512.txt" 2>&1
 cp "$O/kt/run_kernel_stats.csv" "$O/kernel_stats_b1_256x512.csv"; rm -rf "$O/kt"
-for cfg in "b8_256x512:--batch 8 --steps 20 --warmup 5" "b8_368x1232:--batch 8 --size 368x1232 --steps 8 --warmup 3"; do
-  tag=${cfg%%:*}; args=${cfg#*:}
+# B=8 and 8 x 368x1232: kernel statistics, the timeline of ONE forward from the middle of the timed region (the forwards behind it
+# are the breakdown pass, event-bracketed, and the latency pass, one forward per host synchronisation: 60 forwards from the end),
+# and the overlap account of the side stream (tools/overlap_account.py)
+for cfg in "b8_256x512:--batch 8 --steps 20 --warmup 5:70" "b8_368x1232:--batch 8 --size 368x1232 --steps 8 --warmup 3:64"; do
+  tag=${cfg%%:*}; rest=${cfg#*:}; args=${rest%%:*}; back=${rest##*:}
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_$tag" -o run -- python3 "$R/bench.py" $args --no-cpu-baseline --no-pipelined > /dev/null 2>&1
-  cp "$O/kt_$tag/run_kernel_stats.csv" "$O/kernel_stats_$tag.csv"; rm -rf "$O/kt_$tag"
+  cp "$O/kt_$tag/run_kernel_stats.csv" "$O/kernel_stats_$tag.csv"
+  python3 "$R/tools/timeline.py" "$O/kt_$tag/run_kernel_trace.csv" $back > "$O/timeline_${tag}.txt" 2>&1
+  python3 "$R/tools/overlap_account.py" "$O/kt_$tag/run_kernel_trace.csv" $back 4 > "$O/overlap_account_${tag}.txt" 2>&1
+  rm -rf "$O/kt_$tag"
 done
 # counters: FETCH_SIZE, WRITE_SIZE and the SQ set in separate passes, for the three published workloads
 for cfg in "b1_256x512:" "b8_256x512:--batch 8" "b8_368x1232:--batch 8 --size 368x1232"; do
