@@ -171,6 +171,12 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "mid8_tile"      0 (default: by grid size -- 3 x 8 x 32 voxels once >= 192 such tiles exist and they balance, else 3 x 2 x 32,
  *                    round 5) / 1..4 force k_conv3d_mid8q's tile: 3x2, 1x4, 3x4 (with "mid8_balance"'s residency cap), 3x8
  *                    rows x 32; t2 + 8 t3 addresses stages 2 and 3 separately
+ *   "fork_ext"       1 (default) / 0: the two forks of lws_forward (side stream started behind the feature head / behind stage 1's
+ *                    Conv3D stack) use an event bound to the producer kernel's own completion signal instead of a
+ *                    hipEventRecord marker on the caller's stream (round 5: 1.3 instead of 2.6 us per fork on the chain)
+ *   "tail_at"        -1 (default: 1 -- measured round 5: 0 costs the stage-1 MFMA kernels more than the join it saves) / 0 / 1: the feature-extractor tail conv6 + classif1 (-> the 1/2
+ *                    map of stage 3) is started with conv5 at the first fork (0: ONE join on the caller's stream serves stages 2
+ *                    and 3; a join costs ~5 us of a batch-1 chain) or after stage 1's Conv3D stack (1: beside stage 2)
  *   "warp_form"      residual volumes of stages 2 and 3: 1 (default) = k_volume_l1_warp stages the right-feature window of a
  *                    64-pixel row segment (all channels, zero-filled outside the image) in LDS and computes the 2m - 1
  *                    hypotheses from it; 0 = every tap gathered from global memory (the form a tile falls back to when its

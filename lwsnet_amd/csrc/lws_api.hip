@@ -13,6 +13,7 @@
 namespace lws {
 
 static thread_local char g_err[512] = "";
+thread_local hipEvent_t tl_stop_event = nullptr;
 
 void set_error(const char *fmt, ...)
 {
@@ -224,9 +225,11 @@ static void prof_clear(lws_ctx *h)
 }
 
 // low != nullptr: the soft-argmin is wanted too; *fused tells the caller whether it was done here
+// last_stop (optional): an event that must be complete once the stack's last kernel is -- bound to that kernel's completion
+// signal where the launcher supports it (stop_event_arm, lws_common.h), recorded behind it otherwise
 static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost_out, float *act_a, float *act_b,
                         int B, int D, int hh, int ww, hipStream_t st, float *low = nullptr, float start = 0.f,
-                        bool *fused = nullptr, bool first_done = false)
+                        bool *fused = nullptr, bool first_done = false, hipEvent_t last_stop = nullptr)
 {
     const Stage3d &s = h->stage[stage];
     int rc = LWS_OK;
@@ -252,13 +255,19 @@ static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost
         if (rc) return rc;
         std::swap(src, dst);
     }
-    ProfScope p(h, LWS_KC_CONV3D_LAST, st);
-    if (low != nullptr && conv3d_last_can_fuse(s, D)) {
-        *fused = true;
-        return launch_conv3d_last_softargmin(s, src, cost_in, nullptr, low, start, B, D, hh, ww, st);
+    {
+        ProfScope p(h, LWS_KC_CONV3D_LAST, st);
+        if (last_stop != nullptr) stop_event_arm(last_stop);
+        if (low != nullptr && conv3d_last_can_fuse(s, D)) {
+            *fused = true;
+            rc = launch_conv3d_last_softargmin(s, src, cost_in, nullptr, low, start, B, D, hh, ww, st);
+        } else {
+            if (fused) *fused = false;
+            rc = launch_conv3d_last(s, src, cost_in, cost_out, B, D, hh, ww, st);
+        }
     }
-    if (fused) *fused = false;
-    return launch_conv3d_last(s, src, cost_in, cost_out, B, D, hh, ww, st);
+    if (stop_event_take() != nullptr && rc == LWS_OK) LWS_HIP(hipEventRecord(last_stop, st));   // the launcher did not bind it
+    return rc;
 }
 
 
@@ -439,9 +448,10 @@ static int feature_tail(lws_ctx *h, int N, int H, int W, const WsLayout &L, floa
 
 // If tail != nullptr only the layers up to the 1/8 map run here (stage 1 needs nothing else); the caller runs
 // feature_tail (conv5, conv6, classif1 -> f4, f2) on the `tail` stream later, overlapped with the volume stages.
+// fork_ev (optional, single-head plan only): complete once f8 / pre are -- bound to the last head kernel (stop_event_arm)
 static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, int nA, int nB, int H, int W,
                               const WsLayout &L, float *f8, float *f4, float *f2, hipStream_t st,
-                              hipStream_t tail = nullptr, hipEvent_t *ev = nullptr)
+                              hipStream_t tail = nullptr, hipEvent_t *ev = nullptr, hipEvent_t fork_ev = nullptr)
 {
     const Net2d &n = h->net2d;
     const int N = nA + nB, H2 = half_up(H), W2 = half_up(W), H4 = H2 / 2, W4 = W2 / 2, H8 = H2 / 4, W8 = W2 / 4;
@@ -463,10 +473,12 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
         LWS_FE(launch_conv2d_pair(n.fe[0], n.fe[1], img, nullptr, o + 8 * q2, cnt, H, W, st, img2, n1));         // dres0
         LWS_FE(launch_conv2d_pair(n.fe[2], n.fe[3], o + 8 * q2, o + 8 * q2, o2 + 8 * q2, cnt, H2, W2, st));      // dres1 + o (:179)
         LWS_FE(launch_conv2d_pair(n.fe[4], n.fe[5], o2 + 8 * q2, nullptr, pre + 16 * q4, cnt, H2, W2, st));      // conv1, conv2 -> pre
+        if (fork_ev != nullptr) stop_event_arm(fork_ev);
         LWS_FE(launch_conv2d_pair(n.fe[6], n.fe[7], pre + 16 * q4, nullptr, f8 + 16 * q8, cnt, H4, W4, st));     // conv3, conv4 -> f8
+        if (stop_event_take() != nullptr) LWS_HIP(hipEventRecord(fork_ev, st));                                  // not bound by the launcher
         return LWS_OK;
     };
-    if (tail != nullptr && tail != st && split_heads(h, nB) && h->side2 != nullptr) {
+    if (tail != nullptr && tail != st && split_heads(h, nB) && h->side2 != nullptr && fork_ev == nullptr) {
         // left and right images are independent up to the cost volume: for batches >= 4 pairs the right images'
         // layers run on a second side stream and join before f8 is consumed (measured r01: +4 % at B = 8, but
         // -11 % at B = 1, where the two half-size launches only add dispatch overhead: there they stay batched)
@@ -580,6 +592,8 @@ struct DeferState {
     // upsample(low[0]) at the same pixels and writes it out too (two-level DeferredMap).  pred1_unwritten: nobody has yet.
     bool allow_first = false;                // the caller runs the whole forward (lws_forward)
     bool pred1_unwritten = false;
+    hipEvent_t stage1_stop = nullptr;        // lws_forward's second fork: complete once stage 1's Conv3D stack is (conv3d_stack's last_stop)
+    bool stage1_stop_set = false;
     bool def[3] = {false, false, false};
     const float *low[3] = {nullptr, nullptr, nullptr};
     int lh[3] = {0, 0, 0}, lw[3] = {0, 0, 0};
@@ -708,7 +722,7 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         int D, hh, ww;
         stage_dims(h, s, H, W, D, hh, ww);
         float *low = h->ws + L.low[s];
-        if (s > 0 && feat_ready != nullptr) LWS_HIP(hipStreamWaitEvent(st, feat_ready[s], 0));
+        if (s > 0 && feat_ready != nullptr && feat_ready[s] != nullptr) LWS_HIP(hipStreamWaitEvent(st, feat_ready[s], 0));
         const bool fuse_shift = h->opt.fuse_shift != 0;   // default on (measured r01: +0.3 % at batch 1, +0.7 % at batch 8)
         bool first_done = false;
         if (s == 0 && fuse_shift && shift_first_can_fuse(h->stage[0], feat_c[0])) {
@@ -745,8 +759,9 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         // k_softargmin_upsample launch does soft-argmin AND upsample in one kernel
         const bool defer_first = s == 0 && defer_up && h->opt.fuse_last1 != 0 && ds->allow_first && B <= 2 && H % 2 == 0 && W % 2 == 0;
         rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st, (s > 0 || defer_first) ? low : nullptr, start, &fused,
-                          first_done);                                                                      // :136-138
+                          first_done, s == 0 ? ds->stage1_stop : nullptr);                                  // :136-138
         if (rc) return rc;
+        if (s == 0 && ds->stage1_stop != nullptr) ds->stage1_stop_set = true;
         if (s == 0 && after_stage1_stack) {
             rc = after_stage1_stack();
             if (rc) return rc;
@@ -850,6 +865,7 @@ static int ensure_streams(lws_ctx *h)
     for (int i = 0; i < 3; ++i) LWS_HIP(hipEventCreateWithFlags(&h->ev_feat[i], ef));
     LWS_HIP(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
     LWS_HIP(hipEventCreateWithFlags(&h->ev_right, ef));
+    LWS_HIP(hipEventCreateWithFlags(&h->ev_fork2, ef));
     return LWS_OK;
 }
 
@@ -927,6 +943,8 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"mid8_balance", &h->opt.mid8_balance},
                                                      {"fuse_last1", &h->opt.fuse_last1},
                                                      {"mid8_tile", &h->opt.mid8_tile},
+                                                     {"fork_ext", &h->opt.fork_ext},
+                                                     {"tail_at", &h->opt.tail_at},
                                                      {"fuse_ref_last", &h->opt.fuse_ref_last},
                                                      {"device", &h->device},
                                                      {"mid8_form", &h->opt.mid8_form}};
@@ -951,7 +969,7 @@ int lws_set_option(lws_handle h, const char *name, int value)
     LWS_CHECK_ARG(slot != nullptr, "lws_set_option: unknown option '%s'", name);
     if (strcmp(name, "left_at") == 0)
         LWS_CHECK_ARG(value == -1 || value == 0 || value == 2, "lws_set_option: left_at must be -1 (auto), 0 or 2 (got %d)", value);
-    else if (strcmp(name, "split_heads") == 0 || strcmp(name, "ref_pipe") == 0 || strcmp(name, "fuse_ref_last") == 0)
+    else if (strcmp(name, "split_heads") == 0 || strcmp(name, "ref_pipe") == 0 || strcmp(name, "fuse_ref_last") == 0 || strcmp(name, "tail_at") == 0)
         LWS_CHECK_ARG(value >= -1 && value <= 1, "lws_set_option: %s must be -1 (auto), 0 or 1 (got %d)", name, value);
     else if (strcmp(name, "ref_chunk_mb") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 4096, "lws_set_option: ref_chunk_mb must be in 0..4096 (got %d)", value);
@@ -1064,6 +1082,7 @@ int lws_destroy(lws_handle h)
         (void)hipStreamSynchronize(h->side2);
         (void)hipStreamDestroy(h->side2);
         (void)hipEventDestroy(h->ev_right);
+        if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
     }
     if (h->params && h->owns_params) (void)hipFree(h->params);
     if (h->ws) (void)hipFree(h->ws);
@@ -1361,39 +1380,62 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
         if (multi) LWS_HIP(hipEventRecord(h->ev_join, side));
     }
     float *f8 = h->ws + L.fe_f8, *f4 = h->ws + L.fe_f4, *f2 = h->ws + L.fe_f2;
-    rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st, side, h->ev_feat);       // models.py:110-111
+    // Cross-stream hand-offs cost the stream that carries the chain (tools/micro/event_cost.hip, round 5): a fork by
+    // hipEventRecord 2.6 us, by an event bound to the producer kernel's completion signal 1.3 us (option "fork_ext"); a join --
+    // hipStreamWaitEvent on an event that is not complete when the HOST calls it, which is always the case here because the host
+    // runs a forward ahead of the device -- 5 us, even when the event is long complete by the time the command processor gets
+    // there.  The chain has two forks (after the feature head; after stage 1's Conv3D stack) and three joins (f4 before stage
+    // 2, f2 before stage 3, refinement1_left before the refinement).  Option "tail_at" = 0 starts the whole feature tail at the
+    // first fork: f4 and f2 then share ONE join (before stage 2), at the price of three more short kernels beside stage 1.
+    const bool fork_ext = multi && h->opt.fork_ext != 0 && !split_heads(h, B);
+    // Measured round 5 (profiles/r05/experiments/ab_fork_tail.txt, pairs/s): "tail_at" 0 vs 1 at batch 1: 1,994-2,008 vs
+    // 2,107-2,119 -- the three extra kernels beside stage 1 cost k_conv3d_mid16 1.5-2.7 us per launch (24.4 -> 25.9-27.2 us),
+    // far more than the join they save; 2,534 vs 2,579 at batch 2, 2,888 vs 2,924 at batch 4, 3,053 vs 3,021 at batch 8 (one
+    // sample).  "fork_ext" 1 vs 0 at batch 1: 2,107-2,119 vs 2,093-2,108 (+0.5 %).  Automatic: the tail stays at the second fork.
+    const int tail_at = h->opt.tail_at >= 0 ? h->opt.tail_at : 1;
+    rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st, side, h->ev_feat, fork_ext ? h->ev_feat[0] : nullptr);   // models.py:110-111
     if (rc) return rc;
     const size_t n2 = (size_t)B * 8 * half_up(H) * half_up(W), n4 = n2 / 2, n8 = n2 / 8;   // 8 / 16 / 16 channels
     const float *fl[3] = {f8, f4, f2};
     const float *fr[3] = {f8 + n8, f4 + n4, f2 + n2};
-    // The rest of the feature extractor (f4 for stage 2, f2 for stage 3) is launched on the side stream right after
-    // stage 1's Conv3D stack: it overlaps with stage 1's regression and with stage 2 instead of competing with the
-    // MFMA-bound stage-1 kernels for the CUs.
-    // (conv5 -> f4 is one short kernel: it goes to the side stream at once, so stage 2 never waits for it.)
+    // The rest of the feature extractor (f4 for stage 2, f2 for stage 3) runs on the side stream.  conv5 -> f4 is one short
+    // kernel and goes there at once, so stage 2 never waits for it; conv6 + classif1 -> f2 follow it ("tail_at" = 0) or start
+    // after stage 1's Conv3D stack ("tail_at" = 1: beside stage 1's regression and stage 2 instead of beside the MFMA-bound
+    // stage-1 kernels).
     if (multi) {
-        LWS_HIP(hipEventRecord(h->ev_feat[0], st));
+        if (!fork_ext) LWS_HIP(hipEventRecord(h->ev_feat[0], st));
         LWS_HIP(hipStreamWaitEvent(side, h->ev_feat[0], 0));
     }
-    rc = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, 1);
+    rc = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, tail_at == 0 ? 3 : 1);
     if (rc) return rc;
+    DeferState ds;
+    ds.allow_last = refine_can_defer(h);
+    ds.allow_first = true;
+    if (fork_ext) ds.stage1_stop = h->ev_fork2;
     auto launch_tail = [&]() -> int {
+        if (tail_at == 0 && left_at != 2) return LWS_OK;          // nothing is started here
         if (multi) {
-            LWS_HIP(hipEventRecord(h->ev_feat[0], st));
-            LWS_HIP(hipStreamWaitEvent(side, h->ev_feat[0], 0));
+            hipEvent_t fe = h->ev_feat[0];
+            if (ds.stage1_stop_set)
+                fe = ds.stage1_stop;                              // already bound to (or recorded behind) stage 1's last kernel
+            else
+                LWS_HIP(hipEventRecord(fe, st));
+            LWS_HIP(hipStreamWaitEvent(side, fe, 0));
         }
-        int r2 = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, 2);
-        if (r2) return r2;
+        if (tail_at != 0) {
+            int r2 = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, 2);
+            if (r2) return r2;
+        }
         if (left_at == 2) {
-            r2 = refine_left(h, left, B, H, W, L, side);
+            int r2 = refine_left(h, left, B, H, W, L, side);
             if (r2) return r2;
             if (multi) LWS_HIP(hipEventRecord(h->ev_join, side));
         }
         return LWS_OK;
     };
-    DeferState ds;
-    ds.allow_last = refine_can_defer(h);
-    ds.allow_first = true;
-    rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st, multi ? h->ev_feat : nullptr, launch_tail, &ds);   // :115-156
+    // joins: f4 before stage 2 and f2 before stage 3 -- or, with the whole tail issued together, both before stage 2
+    hipEvent_t ready[3] = {nullptr, tail_at == 0 ? h->ev_feat[2] : h->ev_feat[1], tail_at == 0 ? nullptr : h->ev_feat[2]};
+    rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st, multi ? ready : nullptr, launch_tail, &ds);   // :115-156
     if (rc) return rc;
     if (multi) LWS_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     return refine_rest(h, pred_out[2], B, H, W, L, pred_out[3], st, &ds, pred_out[1]);       // :159-162

@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <atomic>
@@ -33,6 +34,30 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
     } while (0)
 
 #define LWS_LAUNCH_CHECK() LWS_HIP(hipGetLastError())
+
+// A cross-stream fork without a marker packet on the producer's queue (round 5).  hipEventRecord behind a kernel costs the
+// stream that carries the chain 1.1 us (2.6 us once another stream really waits on it); an event bound to the kernel's OWN
+// completion signal -- hipExtLaunchKernelGGL(..., stopEvent) -- costs 0.0 / 1.3 us (tools/micro/event_cost.hip: extstop, extfork;
+// profiles/r05/micro_event_cost.txt).  Protocol: the caller arms the event (stop_event_arm), calls a launcher, and records the
+// event the ordinary way if the launcher's kernel did not take it (stop_event_take() != nullptr) -- so a launch path that does
+// not know about stop events stays correct.  Launch sites that honour it use LWS_LAUNCH_STOP instead of hipLaunchKernelGGL.
+// Thread-local: handles are driven from their own host threads (lws_pool).
+extern thread_local hipEvent_t tl_stop_event;
+static inline void stop_event_arm(hipEvent_t e) { tl_stop_event = e; }
+static inline hipEvent_t stop_event_take()
+{
+    hipEvent_t e = tl_stop_event;
+    tl_stop_event = nullptr;
+    return e;
+}
+#define LWS_LAUNCH_STOP(kernel, grid, block, lds, st, ...)                                                  \
+    do {                                                                                                    \
+        hipEvent_t se_ = ::lws::stop_event_take();                                                          \
+        if (se_ != nullptr)                                                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, nullptr, se_, 0, __VA_ARGS__);              \
+        else                                                                                                \
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                  \
+    } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -187,6 +212,8 @@ struct lws_ctx {
         int warp_form = 1;         // residual volumes: 1 = right-feature window of a 64-pixel row segment staged in LDS, 0 = every tap gathered from global memory
         int fuse_last1 = 1;        // batches <= 2: stage 1's last Conv3D layer + soft-argmin in one launch, pred1 evaluated by its consumers
         int mid8_tile = 0;         // force k_conv3d_mid8q's tile shape (see Stage3d); 0 = automatic
+        int fork_ext = 1;          // the two forks of lws_forward bound to their producer kernel's completion signal (no marker packet)
+        int tail_at = -1;          // feature-extractor tail (conv6, classif1 -> f2): 0 = with conv5 at the first fork (ONE join for f4 and f2), 1 = at the second fork (beside stage 2), -1 = automatic (1: measured round 5)
         int fuse_ref_last = -1;    // refinement2's last block + the 32 -> 1 convolution + pred3 in one launch: -1 = batch 1 only, 0 / 1
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
     } opt;
@@ -217,6 +244,7 @@ struct lws_ctx {
     hipEvent_t ev_feat[3] = {nullptr, nullptr, nullptr};   // f8 / f4 / f2 complete
     hipStream_t side2 = nullptr;                            // right-image feature layers
     hipEvent_t ev_right = nullptr;
+    hipEvent_t ev_fork2 = nullptr;                          // second fork of lws_forward (after stage 1's Conv3D stack)
 };
 
 namespace lws {

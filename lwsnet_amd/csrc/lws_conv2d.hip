@@ -499,8 +499,8 @@ static int conv2d_pair_mfma_launch(const Conv2dLayer &a, const Conv2dLayer &b, c
     using Cfg = PairMfmaCfg<CIN>;
     const size_t lds = (size_t)Cfg::LDS_FLOATS * sizeof(float);
     dim3 grid(cdiv(WA, 8), cdiv(HA, 8), N), block(Cfg::NT);
-    hipLaunchKernelGGL((k_conv2d_pair_mfma<CIN>), grid, block, lds, st, in, in2, n1, a.w_mfma, a.bn_s, a.bn_t, a.relu ? 1 : 0,
-                       b.w_mfma, b.bn_s, b.bn_t, b.relu ? 1 : 0, out, H, W, HA, WA);
+    LWS_LAUNCH_STOP((k_conv2d_pair_mfma<CIN>), grid, block, lds, st, in, in2, n1, a.w_mfma, a.bn_s, a.bn_t, a.relu ? 1 : 0,
+                    b.w_mfma, b.bn_s, b.bn_t, b.relu ? 1 : 0, out, H, W, HA, WA);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }

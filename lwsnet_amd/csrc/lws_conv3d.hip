@@ -1698,8 +1698,8 @@ static int last_launch(const Stage3d &s, const float *act, const float *skip, fl
     }
     const int tiles_x = cdiv(w, TX), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
-    hipLaunchKernelGGL((k_conv3d_last<C3, TD, TY, TX, FUSE>), grid, block, Cfg::LDS_BYTES, st, act, s.layers.back().w,
-                       skip, cost_out, low, start, D, h, w, tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
+    LWS_LAUNCH_STOP((k_conv3d_last<C3, TD, TY, TX, FUSE>), grid, block, Cfg::LDS_BYTES, st, act, s.layers.back().w,
+                    skip, cost_out, low, start, D, h, w, tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }

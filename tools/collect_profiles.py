@@ -30,6 +30,9 @@ for n in copied:
             continue
         cb = d.get("cpu_baseline") or {}
         r = d.get("roofline") or {}
+        if d.get("value") is None:                       # --one-gpu / --dry-run-cpu lines carry no throughput
+            print(f"{n:36s} value null ({(d.get('shared_one_gpu') or {}).get('pairs_per_s_both_ranks_on_one_gpu')} pairs/s with the ranks sharing one GPU)")
+            continue
         print(f"{n:36s} {d['value']:8.1f} pairs/s {d['ms_per_step']:8.3f} ms  mid16 {r.get('achieved')} TF ({r.get('avg_launch_us')} us) "
               f"frac {r.get('frac')} step_frac {r.get('step_frac')} traffic {r.get('traffic')}  cpu {cb.get('value')}")
 f = os.path.join(dst, "kernel_stats_b1_256x512.csv")

@@ -7,9 +7,17 @@
 //   join      a short kernel + hipEventRecord(f_i) on s1 issued FIRST (complete long before), hipStreamWaitEvent(s0, f_i) before kernel i
 //   wrval     hipStreamWriteValue32(s0, flag_i) after every kernel instead of the event record
 //   waitval   s1 writes flag_i early; hipStreamWaitValue32(s0, flag_i, ==) before kernel i instead of the event wait
+// Round 5 (the host of lws_forward runs a whole forward AHEAD of the device, so at hipStreamWaitEvent time nothing is complete):
+//   extstop   the event bound to the kernel's own completion signal: hipExtLaunchKernelGGL(..., stopEvent = e_i) -- no marker packet
+//   extfork   extstop + hipStreamWaitEvent(s1, e_i) + a short kernel on s1
+//   joinlive  fork, and kernel i of s0 waits for the short s1 kernel that was forked after kernel i-2 (f_{i-2}): the event is
+//             NOT complete when the host calls hipStreamWaitEvent (a barrier packet is really queued) but IS when the command
+//             processor reaches it -- what lws_forward's three joins look like; its cost = joinlive - fork
+//   extjoin   extfork + the same joins
 // Output: us per kernel of the chain and the extra us per hand-off against `base`.
 //   hipcc --offload-arch=gfx950 -O3 -o event_cost tools/micro/event_cost.hip && ./event_cost
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <vector>
 
@@ -54,10 +62,10 @@ int main()
     hipEvent_t t0, t1;
     CK(hipEventCreate(&t0));
     CK(hipEventCreate(&t1));
-    const char *names[] = {"base", "record", "fork", "join", "wrval", "waitval"};
+    const char *names[] = {"base", "record", "fork", "join", "wrval", "waitval", "extstop", "extfork", "joinlive", "extjoin"};
     double base_us = 0;
-    for (int mode = 0; mode < 6; ++mode) {
-        if (mode >= 4 && !have_val) continue;
+    for (int mode = 0; mode < 10; ++mode) {
+        if ((mode == 4 || mode == 5) && !have_val) continue;
         float best = 1e30f;
         for (int rep = 0; rep < REP; ++rep) {
             if (have_val) CK(hipMemset(flags, 0, N * 4 * 2));
@@ -73,11 +81,16 @@ int main()
             for (int i = 0; i < N; ++i) {
                 if (mode == 3) CK(hipStreamWaitEvent(s0, fv[i], 0));
                 if (mode == 5) CK(hipStreamWaitValue32(s0, flags + i, 1u, hipStreamWaitValueEq, 0xffffffffu));
-                hipLaunchKernelGGL(k_short, dim3(256), dim3(64), 0, s0, a, SPIN);
-                if (mode == 1 || mode == 2) CK(hipEventRecord(ev[i], s0));
-                if (mode == 2) {
+                if ((mode == 8 || mode == 9) && i >= 2) CK(hipStreamWaitEvent(s0, fv[i - 2], 0));
+                if (mode == 6 || mode == 7 || mode == 9)
+                    hipExtLaunchKernelGGL(k_short, dim3(256), dim3(64), 0, s0, nullptr, ev[i], 0, a, SPIN);
+                else
+                    hipLaunchKernelGGL(k_short, dim3(256), dim3(64), 0, s0, a, SPIN);
+                if (mode == 1 || mode == 2 || mode == 8) CK(hipEventRecord(ev[i], s0));
+                if (mode == 2 || mode == 7 || mode == 8 || mode == 9) {
                     CK(hipStreamWaitEvent(s1, ev[i], 0));
                     hipLaunchKernelGGL(k_short, dim3(1), dim3(64), 0, s1, b, 10);
+                    if (mode == 8 || mode == 9) CK(hipEventRecord(fv[i], s1));
                 }
                 if (mode == 4) CK(hipStreamWriteValue32(s0, flags + N + i, 1u, 0));
             }
