@@ -1564,6 +1564,8 @@ static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out,
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
     hipLaunchKernelGGL((k_conv3d_mid8<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w,
+                       // (write-through stores for outputs <= 40 MB, as k_ref_dws uses them: measured round 5, no change at batch 1
+                       // -- 2,091-2,101 vs 2,096-2,103 pairs/s -- so the stores stay write-back)
                        s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, /*wt=*/0,
                        2 * tiles_d + (s.dfast ? 1 : 0));
     LWS_LAUNCH_CHECK();
@@ -1592,6 +1594,8 @@ static int mid8q_launch(const Stage3d &s, int layer, const float *in, float *out
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
     hipLaunchKernelGGL((k_conv3d_mid8q<TD, TY>), grid, block, lds, st, in, s.layers[layer].w + MID8_PACK,
+                       // (write-through stores for outputs <= 40 MB, as k_ref_dws uses them: measured round 5, no change at batch 1
+                       // -- 2,091-2,101 vs 2,096-2,103 pairs/s -- so the stores stay write-back)
                        s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, /*wt=*/0,
                        2 * tiles_d + (s.dfast ? 1 : 0));
     LWS_LAUNCH_CHECK();
