@@ -165,9 +165,11 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "ref_pipe"       -1 (default: on from four chunks up), 0 / 1: consecutive refinement chunks alternate between the caller's
  *                    stream and the handle's side stream, one chunk's memory-bound blocks beside the other's 64 -> 32 convolution
  *                    (r03: 810 -> 833 pairs/s at 8 x 368x1232; two chunks only, 8 x 256x512: 2,958 -> 2,930, hence the default)
- *   "mid8_balance"   1 (default) / 0: on grids of at most four small (3 x 4 x 32) tiles per CU, k_conv3d_mid8q takes the small
- *                    tile and asks for 160 KB / k of LDS so that exactly k workgroups are resident per CU (one 256x512 pair at
- *                    stage 3: 768 tiles = 3 per CU instead of 384 large tiles = 2 on half of the CUs); lws_pool workers run with 0
+ *   "mid8_balance"   1 (default) / 0: on grids of at most four small tiles per CU k_conv3d_mid8q takes the small tile whenever
+ *                    that is the shorter schedule of the fullest CU (one 256x512 pair at stage 3: 768 small 3 x 4 x 32-voxel units
+ *                    = 3 per CU instead of 384 large tiles = 2 on half of the CUs); lws_pool workers run with 0.  (Round 4 also
+ *                    capped the residency through the LDS request; since round 5 the small tile is 3 x 2 x 32 and uncapped --
+ *                    "mid8_tile" = 3 brings the capped 3 x 4 x 32 form back)
  *   "mid8_tile"      0 (default: by grid size -- 3 x 8 x 32 voxels once >= 192 such tiles exist and they balance, else 3 x 2 x 32,
  *                    round 5) / 1..4 force k_conv3d_mid8q's tile: 3x2, 1x4, 3x4 (with "mid8_balance"'s residency cap), 3x8
  *                    rows x 32; t2 + 8 t3 addresses stages 2 and 3 separately

@@ -1346,6 +1346,7 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     rc = ensure_ws(h, L.total_all);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    (void)stop_event_take();   // (an error return of an earlier call on this thread may have left a stop event armed)
     // profiler sampling (lws_profile_sample): only every n-th forward call records events
     struct MaskGuard {
         lws_ctx *h;

@@ -226,3 +226,39 @@ def test_outputs_answer_the_callers_paddle_spellings():
     assert np.array_equal(np.asarray(o), d) and np.array_equal(o[0, 0].numpy(), d[0, 0])
     assert isinstance(o + 1.0, torch.Tensor)                                  # still a torch tensor for everything else
     assert np.array_equal(torch.from_dlpack(o).numpy(), d)                    # zero-copy hand-over to other frameworks
+
+
+def test_overlap_account_on_a_synthetic_trace(tmp_path):
+    """tools/overlap_account.py (the evidence behind DESIGN.md's "co-resident kernels time-share the CUs" statement): on a
+    synthetic kernel trace whose side kernel runs fully beside a chain kernel without slowing it, the tool must report both
+    kernels at their alone durations and 2.00x inside the two-queue windows; with the chain kernel stretched by exactly the side
+    kernel's length (pure time sharing) it must report 1.00x."""
+    import csv
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    for stretch, want in ((0, "2.00x"), (10, "1.00x")):
+        rows, t = [], 0
+        for f in range(40):
+            over = f % 2 == 0
+            for name, dur in (("void lws::k_conv2d_pair<3, 4, 8, 2>(float)", 10), ("void lws::k_a(float)", 20), ("void lws::k_b(float)", 30)):
+                d = dur + (stretch if (over and name.endswith("k_b(float)")) else 0)
+                rows.append(dict(Kernel_Name=name, Queue_Id=1, Start_Timestamp=t, End_Timestamp=t + d * 1000, Grid_Size_X=1, Grid_Size_Y=1, Grid_Size_Z=1))
+                if over and name.endswith("k_b(float)"):
+                    # the side kernel alone takes 10 us; beside k_b it takes 10 (no interference) or 20 (time sharing)
+                    sd = 10 if stretch == 0 else 20
+                    rows.append(dict(Kernel_Name="void lws::k_side(float)", Queue_Id=2, Start_Timestamp=t + 5000, End_Timestamp=t + 5000 + sd * 1000,
+                                     Grid_Size_X=1, Grid_Size_Y=1, Grid_Size_Z=1))
+                t += d * 1000
+            # an un-overlapped launch of the side kernel per forward, so that its alone duration is known
+            rows.append(dict(Kernel_Name="void lws::k_side(float)", Queue_Id=2, Start_Timestamp=t, End_Timestamp=t + 10000, Grid_Size_X=1, Grid_Size_Y=1, Grid_Size_Z=1))
+            t += 10000
+        path = tmp_path / f"kt_{stretch}.csv"
+        with open(path, "w", newline="") as fh:
+            w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "overlap_account.py"), str(path), "20", "4"], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr
+        assert want in p.stdout, p.stdout

@@ -12,7 +12,9 @@ forwards of the timed region, accounts every kernel launch as
 and then sums, over the windows in which two queues were busy at once,
 
     wall        the length of those windows
-    work        the alone-equivalent time of the kernel parts that ran inside them (duration share x alone / in-situ)
+    work        the alone-equivalent progress the kernels made inside them: for every kernel, the time it spent inside such
+                windows minus its excess over its alone duration (a kernel runs at its alone rate while nothing runs beside it,
+                so all of its slowdown is booked to the overlapped part)
 
 work / wall = 1.0 means the overlap is ZERO-SUM (the two kernels time-share the chip: running them back to back would take as
 long); 2.0 would mean both ran at their alone rate.  Per kernel class it prints launches, in-situ and alone microseconds per
@@ -99,20 +101,24 @@ def main():
     active = []
     last = ev[0][0]
     busy = two = 0
-    work_two = 0.0
+    for k in sel:
+        k["in2"] = 0                       # time this kernel spent inside two-queue windows
     for t, d, k in ev:
         if active:
             busy += t - last
             if len({a["q"] for a in active}) >= 2:
                 two += t - last
                 for a in active:
-                    al = alone[a["key"]][0]
-                    work_two += (t - last) * (al / a["dur"] if a["dur"] else 0.0)
+                    a["in2"] += t - last
         last = t
         if d == 1:
             active.append(k)
         else:
             active.remove(k)
+    work_two = 0.0
+    for k in sel:
+        excess = max(0.0, k["dur"] - alone[k["key"]][0])
+        work_two += max(0.0, k["in2"] - excess)
     span = (sel[-1]["e"] - sel[0]["s"]) / 1e3 / nf
     print(f"per forward: span {span:.1f} us, some queue busy {busy / 1e3 / nf:.1f} us, two queues busy {two / 1e3 / nf:.1f} us")
     print(f"             sum of in-situ durations {tot_d:.1f} us, sum of alone durations {tot_a:.1f} us")
