@@ -761,25 +761,38 @@ __global__ __launch_bounds__(256, 4) void k_ref_dws(const float *__restrict__ in
     }
     LWS_STAMPK(5, 1);
 
-    // 2. depthwise: tile pixel p = (tid >> 3) + 32 i  ->  row (tid >> 7) + 2 i, column (tid >> 3) & 15
+    // 2. depthwise: thread = (4-channel group c4, column x, row group rg): the four tile pixels (4 rg + j, x), j = 0..3.  The six
+    //    halo rows those pixels read are walked ONCE (round 5): row rr feeds pixel j as its tap row kh = rr - j, so every pixel
+    //    still receives its taps (kh, kw) ascending -- the chain of the contract -- from 18 ds_read_b128 per thread instead of
+    //    the 36 of one-pixel-at-a-time (the phase is LDS-bandwidth-bound: four workgroups per CU, 2.9 k cycles each, r05 stamps)
     {
         const int q = c4 >> 2, a_ = c4 & 3;
-        const float4 *src = sA + c4 * DWS_SA + (tid >> 7) * RH_X + ((tid >> 3) & 15);
-        float *dst = reinterpret_cast<float *>(sB + (4 * q) * DWS_SB + (tid >> 3)) + a_;
+        const int x = (tid >> 3) & 15, rg = tid >> 7;
+        const float4 *src = sA + c4 * DWS_SA + (4 * rg) * RH_X + x;
+        float4 acc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+        for (int rr = 0; rr < 6; ++rr) {
+            const float4 t0 = src[rr * RH_X], t1 = src[rr * RH_X + 1], t2 = src[rr * RH_X + 2];
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    fma4(acc, src[(2 * i + kh) * RH_X + kw], wd[kh * 3 + kw]);   // four channels: two v_pk_fma_f32
+            for (int j = 0; j < 4; ++j) {
+                const int kh = rr - j;
+                if (kh >= 0 && kh < 3) {
+                    fma4(acc[j], t0, wd[kh * 3 + 0]);        // four channels: two v_pk_fma_f32
+                    fma4(acc[j], t1, wd[kh * 3 + 1]);
+                    fma4(acc[j], t2, wd[kh * 3 + 2]);
                 }
-            // channel 16q + 4a_ + e -> plane 4q + e, element a_ (the 4x4 transpose the MFMA B operand wants)
-            dst[(0 * DWS_SB + 32 * i) * 4] = acc.x;
-            dst[(1 * DWS_SB + 32 * i) * 4] = acc.y;
-            dst[(2 * DWS_SB + 32 * i) * 4] = acc.z;
-            dst[(3 * DWS_SB + 32 * i) * 4] = acc.w;
+            }
+        }
+        // channel 16q + 4a_ + e -> plane 4q + e, element a_ (the 4x4 transpose the MFMA B operand wants)
+        float *dst = reinterpret_cast<float *>(sB + (4 * q) * DWS_SB + (4 * rg) * RT_X + x) + a_;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dst[(0 * DWS_SB + RT_X * j) * 4] = acc[j].x;
+            dst[(1 * DWS_SB + RT_X * j) * 4] = acc[j].y;
+            dst[(2 * DWS_SB + RT_X * j) * 4] = acc[j].z;
+            dst[(3 * DWS_SB + RT_X * j) * 4] = acc[j].w;
         }
     }
     __syncthreads();
