@@ -225,11 +225,12 @@ static void prof_clear(lws_ctx *h)
 }
 
 // low != nullptr: the soft-argmin is wanted too; *fused tells the caller whether it was done here
-// last_stop (optional): an event that must be complete once the stack's last kernel is -- bound to that kernel's completion
-// signal where the launcher supports it (stop_event_arm, lws_common.h), recorded behind it otherwise
+// last_stop (optional): an event that must be complete once the stack's last kernel is (stop_after = 0) or once its
+// stop_after-th middle layer is -- bound to that kernel's completion signal where the launcher supports it (stop_event_arm,
+// lws_common.h), recorded behind it otherwise
 static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost_out, float *act_a, float *act_b,
                         int B, int D, int hh, int ww, hipStream_t st, float *low = nullptr, float start = 0.f,
-                        bool *fused = nullptr, bool first_done = false, hipEvent_t last_stop = nullptr)
+                        bool *fused = nullptr, bool first_done = false, hipEvent_t last_stop = nullptr, int stop_after = 0)
 {
     const Stage3d &s = h->stage[stage];
     int rc = LWS_OK;
@@ -240,6 +241,7 @@ static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost
     if (rc) return rc;
     float *src = act_a, *dst = act_b;
     for (int j = 1; j <= h->cfg.layers_3d; ++j) {
+        if (last_stop != nullptr && j == stop_after) stop_event_arm(last_stop);
         if (s.c3 != 8 && ((h->prof_mask >> LWS_KC_CONV3D_MID16) & 1u) && h->prof.size() < kMaxProfRecords) {
             // dominant kernel: timed by its own begin / end timestamps, not by events around the launch
             lws_prof_rec rec;
@@ -254,10 +256,11 @@ static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost
         }
         if (rc) return rc;
         std::swap(src, dst);
+        if (last_stop != nullptr && j == stop_after && stop_event_take() != nullptr) LWS_HIP(hipEventRecord(last_stop, st));
     }
     {
         ProfScope p(h, LWS_KC_CONV3D_LAST, st);
-        if (last_stop != nullptr) stop_event_arm(last_stop);
+        if (last_stop != nullptr && stop_after == 0) stop_event_arm(last_stop);
         if (low != nullptr && conv3d_last_can_fuse(s, D)) {
             *fused = true;
             rc = launch_conv3d_last_softargmin(s, src, cost_in, nullptr, low, start, B, D, hh, ww, st);
@@ -266,7 +269,7 @@ static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost
             rc = launch_conv3d_last(s, src, cost_in, cost_out, B, D, hh, ww, st);
         }
     }
-    if (stop_event_take() != nullptr && rc == LWS_OK) LWS_HIP(hipEventRecord(last_stop, st));   // the launcher did not bind it
+    if (stop_after == 0 && stop_event_take() != nullptr && rc == LWS_OK) LWS_HIP(hipEventRecord(last_stop, st));   // the launcher did not bind it
     return rc;
 }
 
@@ -593,6 +596,7 @@ struct DeferState {
     bool allow_first = false;                // the caller runs the whole forward (lws_forward)
     bool pred1_unwritten = false;
     hipEvent_t stage1_stop = nullptr;        // lws_forward's second fork: complete once stage 1's Conv3D stack is (conv3d_stack's last_stop)
+    int stage1_stop_after = 0;               // ... or once its k-th middle layer is (option "fork2_after")
     bool stage1_stop_set = false;
     bool def[3] = {false, false, false};
     const float *low[3] = {nullptr, nullptr, nullptr};
@@ -759,7 +763,7 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         // k_softargmin_upsample launch does soft-argmin AND upsample in one kernel
         const bool defer_first = s == 0 && defer_up && h->opt.fuse_last1 != 0 && ds->allow_first && B <= 2 && H % 2 == 0 && W % 2 == 0;
         rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st, (s > 0 || defer_first) ? low : nullptr, start, &fused,
-                          first_done, s == 0 ? ds->stage1_stop : nullptr);                                  // :136-138
+                          first_done, s == 0 ? ds->stage1_stop : nullptr, s == 0 ? ds->stage1_stop_after : 0);   // :136-138
         if (rc) return rc;
         if (s == 0 && ds->stage1_stop != nullptr) ds->stage1_stop_set = true;
         if (s == 0 && after_stage1_stack) {
@@ -944,6 +948,7 @@ static int *option_slot(lws_ctx *h, const char *name)
                                                      {"fuse_last1", &h->opt.fuse_last1},
                                                      {"mid8_tile", &h->opt.mid8_tile},
                                                      {"fork_ext", &h->opt.fork_ext},
+                                                     {"fork2_after", &h->opt.fork2_after},
                                                      {"tail_at", &h->opt.tail_at},
                                                      {"fuse_ref_last", &h->opt.fuse_ref_last},
                                                      {"device", &h->device},
@@ -981,6 +986,8 @@ int lws_set_option(lws_handle h, const char *name, int value)
     }
     else if (strcmp(name, "mid8_form") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 2, "lws_set_option: mid8_form must be 0, 1 or 2 (got %d)", value);
+    else if (strcmp(name, "fork2_after") == 0)
+        LWS_CHECK_ARG(value >= -1 && value <= 16, "lws_set_option: fork2_after must be in -1..16 (got %d)", value);
     else if (strcmp(name, "mid8_tile") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 39 && value % 8 <= 4, "lws_set_option: mid8_tile must be t or t2 + 8 * t3 with t in 0..4 (got %d)", value);
     else
@@ -1412,7 +1419,21 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     DeferState ds;
     ds.allow_last = refine_can_defer(h);
     ds.allow_first = true;
-    if (fork_ext) ds.stage1_stop = h->ev_fork2;
+    // Where the second fork sits (option "fork2_after": k = behind stage 1's k-th middle layer, 0 = behind its last layer, -1 =
+    // automatic).  Measured round 5 (profiles/r05/experiments/ab_fork2_after.txt, pairs/s, behind the last layer | the 4th | the
+    // 3rd middle layer): batch 1 2,109-2,111 | 2,118-2,126 | 2,076-2,082; batch 2 2,588-2,590 | 2,579-2,597 | 2,597-2,606; batch 4
+    // 2,882-2,938 | 2,958-2,964 | 2,958-2,964; batch 8 3,049-3,055 | 3,051-3,062 | 3,066-3,072; 8 x 368x1232 847-848 | 847-852 |
+    // 854-855: one middle layer of company costs stage 1 less than the side branch gains by starting earlier, two do at batch 1.
+    // Automatic: behind the last middle layer at batch 1, behind the one before it from batch 2 up.  The event rides on that
+    // kernel's completion signal ("fork_ext") or is recorded behind it: conv3d_stack handles both.
+    const int L3 = h->cfg.layers_3d;
+    int fork2 = h->opt.fork2_after;
+    if (fork2 < 0) fork2 = B <= 1 ? L3 : (L3 >= 2 ? L3 - 1 : L3);
+    if (fork2 > L3) fork2 = 0;
+    if (multi && (fork_ext || fork2 != 0)) {
+        ds.stage1_stop = h->ev_fork2;
+        ds.stage1_stop_after = fork2;
+    }
     auto launch_tail = [&]() -> int {
         if (tail_at == 0 && left_at != 2) return LWS_OK;          // nothing is started here
         if (multi) {

@@ -1520,9 +1520,9 @@ static int mid16_launch(const Stage3d &s, int layer, const float *in, float *out
                               reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
                               s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt, 2 * tiles_d + (s.dfast ? 1 : 0));
     } else {
-        hipLaunchKernelGGL((k_conv3d_mid16<C3, TD, TY, WR, WM>), grid, block, Cfg::LDS_BYTES, st, in,
-                           reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
-                           s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt, 2 * tiles_d + (s.dfast ? 1 : 0));
+        LWS_LAUNCH_STOP((k_conv3d_mid16<C3, TD, TY, WR, WM>), grid, block, Cfg::LDS_BYTES, st, in,
+                        reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
+                        s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt, 2 * tiles_d + (s.dfast ? 1 : 0));
     }
     LWS_LAUNCH_CHECK();
     return LWS_OK;

@@ -102,7 +102,7 @@ def test_options_validate_names_and_ranges(hip_lib):
     rc, h = _create(hip_lib)
     assert rc == 0
     v = ctypes.c_int(123)
-    for name, default in [(b"left_at", -1), (b"split_heads", -1), (b"fuse_shift", 1), (b"fuse_first", 1), (b"defer_upsample", 1), (b"mid8_form", 1), (b"side_streams", 1), (b"conv3d_order", 1), (b"ref_chunk_mb", 72), (b"ref_pipe", -1), (b"warp_form", 1), (b"mid8_balance", 1), (b"fuse_last1", 1), (b"mid8_tile", 0), (b"fork_ext", 1), (b"tail_at", -1), (b"fuse_ref_last", -1), (b"mid16_form", 0), (b"conv64_form", 0)]:
+    for name, default in [(b"left_at", -1), (b"split_heads", -1), (b"fuse_shift", 1), (b"fuse_first", 1), (b"defer_upsample", 1), (b"mid8_form", 1), (b"side_streams", 1), (b"conv3d_order", 1), (b"ref_chunk_mb", 72), (b"ref_pipe", -1), (b"warp_form", 1), (b"mid8_balance", 1), (b"fuse_last1", 1), (b"mid8_tile", 0), (b"fork_ext", 1), (b"fork2_after", -1), (b"tail_at", -1), (b"fuse_ref_last", -1), (b"mid16_form", 0), (b"conv64_form", 0)]:
         assert hip_lib.lws_get_option(h, name, ctypes.byref(v)) == 0 and v.value == default
     assert hip_lib.lws_set_option(h, b"left_at", 2) == 0
     assert hip_lib.lws_get_option(h, b"left_at", ctypes.byref(v)) == 0 and v.value == 2
