@@ -176,10 +176,10 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *   "fork_ext"       1 (default) / 0: the two forks of lws_forward (side stream started behind the feature head / behind stage 1's
  *                    Conv3D stack) use an event bound to the producer kernel's own completion signal instead of a
  *                    hipEventRecord marker on the caller's stream (round 5: 1.3 instead of 2.6 us per fork on the chain)
- *   "fork2_after"    -1 (default: behind the last middle layer at batch 1, behind the one before it from batch 2 up) / 0 / k: where
+ *   "fork2_after"    -1 (default: behind the last middle layer) / 0 / k: where
  *                    the second fork of lws_forward sits -- behind stage 1's last Conv3D layer (0: rounds 1-4) or behind its k-th
  *                    middle layer, so that the side branch starts beside the end of the stage-1 stack (round 5: +0.5 % at batch
- *                    1, +0.5-0.8 % at batch 8 and 8 x 368x1232)
+ *                    1; one layer earlier another 0.3-0.6 % from batch 2 up, at the dominant kernel's expense)
  *   "tail_at"        -1 (default: 1 -- measured round 5: 0 costs the stage-1 MFMA kernels more than the join it saves) / 0 / 1: the feature-extractor tail conv6 + classif1 (-> the 1/2
  *                    map of stage 3) is started with conv5 at the first fork (0: ONE join on the caller's stream serves stages 2
  *                    and 3; a join costs ~5 us of a batch-1 chain) or after stage 1's Conv3D stack (1: beside stage 2)

@@ -1423,12 +1423,16 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     // automatic).  Measured round 5 (profiles/r05/experiments/ab_fork2_after.txt, pairs/s, behind the last layer | the 4th | the
     // 3rd middle layer): batch 1 2,109-2,111 | 2,118-2,126 | 2,076-2,082; batch 2 2,588-2,590 | 2,579-2,597 | 2,597-2,606; batch 4
     // 2,882-2,938 | 2,958-2,964 | 2,958-2,964; batch 8 3,049-3,055 | 3,051-3,062 | 3,066-3,072; 8 x 368x1232 847-848 | 847-852 |
-    // 854-855: one middle layer of company costs stage 1 less than the side branch gains by starting earlier, two do at batch 1.
-    // Automatic: behind the last middle layer at batch 1, behind the one before it from batch 2 up.  The event rides on that
-    // kernel's completion signal ("fork_ext") or is recorded behind it: conv3d_stack handles both.
+    // 854-855.  Behind the last middle layer every k_conv3d_mid16 launch still runs undisturbed (the side branch starts beside the
+    // stack's last layer); behind the third, the fourth launch has company: at batch 1 that costs more than the earlier start
+    // gives, from batch 2 up it gives another 0.3-0.6 % of the step while the dominant kernel's in-situ rate drops from 0.78-0.80
+    // to 0.76 of the fp32-MFMA peak (175 -> 182 us per launch at batch 8).  Automatic: behind the last middle layer at every
+    // batch -- the simple rule, and the one that leaves the dominant kernel alone; "fork2_after" = 3 is there for whoever wants
+    // the last half per cent of a large batch.  The event rides on that kernel's completion signal ("fork_ext") or is recorded
+    // behind it: conv3d_stack handles both.
     const int L3 = h->cfg.layers_3d;
     int fork2 = h->opt.fork2_after;
-    if (fork2 < 0) fork2 = B <= 1 ? L3 : (L3 >= 2 ? L3 - 1 : L3);
+    if (fork2 < 0) fork2 = L3;
     if (fork2 > L3) fork2 = 0;
     if (multi && (fork_ext || fork2 != 0)) {
         ds.stage1_stop = h->ev_fork2;
