@@ -180,7 +180,8 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  *                    the second fork of lws_forward sits -- behind stage 1's last Conv3D layer (0: rounds 1-4) or behind its k-th
  *                    middle layer, so that the side branch starts beside the end of the stage-1 stack (round 5: +0.5 % at batch
  *                    1; one layer earlier another 0.3-0.6 % from batch 2 up, at the dominant kernel's expense)
- *   "tail_at"        -1 (default: 1 -- measured round 5: 0 costs the stage-1 MFMA kernels more than the join it saves) / 0 / 1: the feature-extractor tail conv6 + classif1 (-> the 1/2
+ *   "tail_at"        -1 (default: 1 -- measured round 5: 0 costs the stage-1 MFMA kernels more than the join it saves, 2 makes
+ *                    stage 2 wait for its 1/4 map at batch 1) / 0 / 1 / 2 (2: conv5 too starts at the second fork -- no first fork): the feature-extractor tail conv6 + classif1 (-> the 1/2
  *                    map of stage 3) is started with conv5 at the first fork (0: ONE join on the caller's stream serves stages 2
  *                    and 3; a join costs ~5 us of a batch-1 chain) or after stage 1's Conv3D stack (1: beside stage 2)
  *   "warp_form"      residual volumes of stages 2 and 3: 1 (default) = k_volume_l1_warp stages the right-feature window of a

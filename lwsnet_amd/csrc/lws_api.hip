@@ -975,7 +975,7 @@ int lws_set_option(lws_handle h, const char *name, int value)
     if (strcmp(name, "left_at") == 0)
         LWS_CHECK_ARG(value == -1 || value == 0 || value == 2, "lws_set_option: left_at must be -1 (auto), 0 or 2 (got %d)", value);
     else if (strcmp(name, "split_heads") == 0 || strcmp(name, "ref_pipe") == 0 || strcmp(name, "fuse_ref_last") == 0 || strcmp(name, "tail_at") == 0)
-        LWS_CHECK_ARG(value >= -1 && value <= 1, "lws_set_option: %s must be -1 (auto), 0 or 1 (got %d)", name, value);
+        LWS_CHECK_ARG(value >= -1 && value <= (strcmp(name, "tail_at") == 0 ? 2 : 1), "lws_set_option: %s is out of range (got %d)", name, value);
     else if (strcmp(name, "ref_chunk_mb") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 4096, "lws_set_option: ref_chunk_mb must be in 0..4096 (got %d)", value);
     else if (strcmp(name, "device") == 0) {
@@ -1399,9 +1399,15 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     // Measured round 5 (profiles/r05/experiments/ab_fork_tail.txt, pairs/s): "tail_at" 0 vs 1 at batch 1: 1,994-2,008 vs
     // 2,107-2,119 -- the three extra kernels beside stage 1 cost k_conv3d_mid16 1.5-2.7 us per launch (24.4 -> 25.9-27.2 us),
     // far more than the join they save; 2,534 vs 2,579 at batch 2, 2,888 vs 2,924 at batch 4, 3,053 vs 3,021 at batch 8 (one
-    // sample).  "fork_ext" 1 vs 0 at batch 1: 2,107-2,119 vs 2,093-2,108 (+0.5 %).  Automatic: the tail stays at the second fork.
+    // sample).  "fork_ext" 1 vs 0 at batch 1: 2,107-2,119 vs 2,093-2,108 (+0.5 %).  "tail_at" 2 (conv5 too at the second fork, no
+    // first fork; with the second fork behind the last MIDDLE layer conv5 runs beside stage 1's last layer): k_conv3d_mid16 24.1-24.4
+    // instead of 24.3-24.6 us, but stage 2 then waits for its 1/4 map: 2,046-2,082 vs 2,112-2,132 at batch 1; 2,645 vs 2,589 at
+    // batch 2, 2,941 vs 2,952 at batch 4, 3,045 vs 3,040 at batch 8, 843 vs 844 at 8 x 368x1232 (one sample each).
+    // Automatic: conv5 at the first fork, the rest at the second.
     const int tail_at = h->opt.tail_at >= 0 ? h->opt.tail_at : 1;
-    rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st, side, h->ev_feat, fork_ext ? h->ev_feat[0] : nullptr);   // models.py:110-111
+    // ("tail_at" = 2: conv5 too waits for the second fork -- no first fork at all)
+    rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st, side, h->ev_feat,
+                            (fork_ext && tail_at != 2) ? h->ev_feat[0] : nullptr);                       // models.py:110-111
     if (rc) return rc;
     const size_t n2 = (size_t)B * 8 * half_up(H) * half_up(W), n4 = n2 / 2, n8 = n2 / 8;   // 8 / 16 / 16 channels
     const float *fl[3] = {f8, f4, f2};
@@ -1410,12 +1416,14 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     // kernel and goes there at once, so stage 2 never waits for it; conv6 + classif1 -> f2 follow it ("tail_at" = 0) or start
     // after stage 1's Conv3D stack ("tail_at" = 1: beside stage 1's regression and stage 2 instead of beside the MFMA-bound
     // stage-1 kernels).
-    if (multi) {
-        if (!fork_ext) LWS_HIP(hipEventRecord(h->ev_feat[0], st));
-        LWS_HIP(hipStreamWaitEvent(side, h->ev_feat[0], 0));
+    if (tail_at != 2) {
+        if (multi) {
+            if (!fork_ext) LWS_HIP(hipEventRecord(h->ev_feat[0], st));
+            LWS_HIP(hipStreamWaitEvent(side, h->ev_feat[0], 0));
+        }
+        rc = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, tail_at == 0 ? 3 : 1);
+        if (rc) return rc;
     }
-    rc = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, tail_at == 0 ? 3 : 1);
-    if (rc) return rc;
     DeferState ds;
     ds.allow_last = refine_can_defer(h);
     ds.allow_first = true;
@@ -1449,7 +1457,7 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
             LWS_HIP(hipStreamWaitEvent(side, fe, 0));
         }
         if (tail_at != 0) {
-            int r2 = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, 2);
+            int r2 = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, tail_at == 2 ? 3 : 2);
             if (r2) return r2;
         }
         if (left_at == 2) {

@@ -214,7 +214,7 @@ struct lws_ctx {
         int mid8_tile = 0;         // force k_conv3d_mid8q's tile shape (see Stage3d); 0 = automatic
         int fork2_after = -1;      // the second fork: 0 = behind stage 1's last Conv3D layer, k = behind its k-th middle layer, -1 = automatic (the last middle layer)
         int fork_ext = 1;          // the two forks of lws_forward bound to their producer kernel's completion signal (no marker packet)
-        int tail_at = -1;          // feature-extractor tail (conv6, classif1 -> f2): 0 = with conv5 at the first fork (ONE join for f4 and f2), 1 = at the second fork (beside stage 2), -1 = automatic (1: measured round 5)
+        int tail_at = -1;          // feature-extractor tail (conv6, classif1 -> f2): 0 = with conv5 at the first fork (ONE join for f4 and f2), 1 = at the second fork (beside stage 2), 2 = conv5 too at the second fork (no first fork), -1 = automatic (1: measured round 5)
         int fuse_ref_last = -1;    // refinement2's last block + the 32 -> 1 convolution + pred3 in one launch: -1 = batch 1 only, 0 / 1
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
     } opt;

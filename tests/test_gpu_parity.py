@@ -369,7 +369,7 @@ OPTION_PLANS = [{"left_at": 0}, {"left_at": 2}, {"split_heads": 1}, {"split_head
                 {"warp_form": 0}, {"warp_form": 0, "defer_upsample": 0}, {"mid8_balance": 0},
                 {"fuse_last1": 0}, {"fuse_last1": 1, "warp_form": 0},
                 {"fuse_ref_last": 0}, {"fuse_ref_last": 1}, {"mid8_tile": 2}, {"mid8_tile": 3}, {"mid8_tile": 4 + 8 * 1},
-                {"fork_ext": 0}, {"fork2_after": 0}, {"fork2_after": 2, "fork_ext": 0}, {"fork2_after": 1}, {"tail_at": 1}, {"tail_at": 0, "fork_ext": 0, "left_at": 0}, {"tail_at": 1, "split_heads": 1},
+                {"fork_ext": 0}, {"fork2_after": 0}, {"fork2_after": 2, "fork_ext": 0}, {"fork2_after": 1}, {"tail_at": 1}, {"tail_at": 2}, {"tail_at": 2, "fork2_after": 0, "fork_ext": 0}, {"tail_at": 0, "fork_ext": 0, "left_at": 0}, {"tail_at": 1, "split_heads": 1},
                 {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0, "mid8_form": 1}]
 
 
