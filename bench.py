@@ -14,10 +14,19 @@ the launch stream inside the timed region.  `cpu_baseline` is the literal oracle
 the host cores of the same box, N = 1 only; it also carries the numerics account: per-stage max-abs distance of the GPU
 result and of the float32 literal oracle to the float64 literal oracle, for the smooth pair and for a white-noise pair.
 
-`python bench.py --gpus N` without torchrun's environment starts the N-rank job itself (a child
-`python -m torch.distributed.run ...`, before anything touches the GPU) and relays rank 0's JSON line.
-`--dry-run-cpu` runs the same launch / shard / gather / report plumbing on CPU over gloo with a per-pair stand-in for
-the forward (no GPU, nothing measured: "value" is null) -- it exists for tests/test_bench_cpu.py.
+Job control (lwsnet_amd/launch.py).  Under torchrun every rank process is a SUPERVISOR that never touches the GPU: local rank
+0 builds the library once, each supervisor starts its rank's worker as a fresh child in its own process group and watches it
+(`--job-timeout`, exit status, a failure flag shared over a gloo control group), and if the RCCL job fails or hangs anywhere the
+supervisors start ONE fallback job in fresh workers whose gather goes over gloo through host memory, labelled as such in
+`collective.backend`.  Rank 0 always prints exactly one JSON line -- with `"value": null, "error": ...` and a non-zero exit status
+if nothing could be measured.  `python bench.py --gpus N` without torchrun's environment starts that torchrun job itself as a
+child (never an exec) and relays the line.  Workers pass `timeout=120 s` to init_process_group (torch's NCCL watchdog applies it
+to every collective) and fail at once when their LOCAL_RANK has no device.
+With N > 1 (or --config4) the same job also times BASELINE config 4's per-rank shape -- 8 pairs per GPU per step, batch 8 N in
+all -- and reports it under `config4`; `value` stays the 1-pair-per-GPU number so that N = 1 agrees with the single-GPU line.
+`--dry-run-cpu` runs the same launch / supervise / shard / gather / report plumbing on CPU over gloo with a per-pair stand-in
+for the forward (no GPU, nothing measured: "value" is null) -- it exists for tests/test_bench_cpu.py, which also injects a hung
+rank and an init failure (LWS_BENCH_INJECT) to see the watchdog and the labelled fallback.
 """
 import argparse
 import ctypes
@@ -88,20 +97,21 @@ def _with_traffic(roof, B, H, W, maxdisp0, fp16):
     return roof
 
 
-def _self_launch(argv, n):
-    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N-rank job as a CHILD process -- never exec from a
-    process that may touch the GPU -- and relay its output; rank 0 prints the JSON line."""
-    import socket
-    import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
-    env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(cmd, env=env)
+def _inject(point, rank):
+    """Fault injection for tests/test_bench_cpu.py (first attempt only): LWS_BENCH_INJECT = "hang:R", "init-fail:R" or
+    "hang-collective:R" makes rank R hang before the rendezvous, fail at it, or hang right before its first collective;
+    LWS_BENCH_INJECT_ATTEMPTS=all extends it to the fallback attempt (the job then ends with the error line)."""
+    spec = os.environ.get("LWS_BENCH_INJECT", "")
+    if not spec or (os.environ.get("LWS_BENCH_ATTEMPT", "0") != "0" and os.environ.get("LWS_BENCH_INJECT_ATTEMPTS") != "all"):
+        return
+    what, _, who = spec.partition(":")
+    if what != point or int(who or 0) != rank:
+        return
+    if what == "init-fail":
+        raise RuntimeError(f"injected init failure on rank {rank} (LWS_BENCH_INJECT)")
+    sys.stderr.write(f"[bench worker {rank}] injected hang at '{point}' (LWS_BENCH_INJECT)\n")
+    while True:
+        time.sleep(3600)
 
 
 def _dry_forward(left, right):
@@ -112,57 +122,70 @@ def _dry_forward(left, right):
 
 def dry_run(args, rank, world):
     """--dry-run-cpu: the N-rank launch, the per-rank shard of seeded pairs, the ONE gather to rank 0, the barrier-
-    bracketed clock and the report -- with a CPU stand-in instead of the HIP forward.  Nothing is measured."""
+    bracketed clock and the report -- with a CPU stand-in instead of the HIP forward.  Nothing is measured.  Like the measured
+    job it runs the main leg (--batch pairs per rank per step) and, for N > 1 or --config4, config 4's 8 pairs per rank."""
     import torch.distributed as dist
     from lwsnet_amd import dist as ldist
     from lwsnet_amd.synth import make_batch
-    B = args.batch
-    left_np, right_np = make_batch(B, 16, 32, first_index=rank * B)
-    left, right = torch.from_numpy(left_np), torch.from_numpy(right_np)
     grouped = dist.is_initialized()
-    # the staged gather of the measured path (lwsnet_amd.dist.StagedGather), 2 steps per gather so that full buffers, the
-    # alternation of the two staging buffers and the tail flush all occur; step k "sees" pairs shifted by k so that a
-    # stale or misplaced slot cannot pass the check below
-    sg = ldist.StagedGather(B, 16, 32, 2, torch.device("cpu"))
-    sg.warm()                                            # (as the measured path does: first-collective set-up outside the clock)
-    nsteps = args.warmup + args.steps
-    if grouped:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for k in range(nsteps):
-        pred = _dry_forward(left + k, right)
-        sg.slot().copy_(pred[3])
-        sg.commit()
-    sg.flush()
-    if grouped:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ok = None
+
+    def leg(B, steps, warmup):
+        left_np, right_np = make_batch(B, 16, 32, first_index=rank * B)
+        left, right = torch.from_numpy(left_np), torch.from_numpy(right_np)
+        # the staged gather of the measured path (lwsnet_amd.dist.StagedGather), 2 steps per gather so that full buffers, the
+        # alternation of the two staging buffers and the tail flush all occur; step k "sees" pairs shifted by k so that a
+        # stale or misplaced slot cannot pass the check below
+        sg = ldist.StagedGather(B, 16, 32, 2, torch.device("cpu"))
+        sg.warm()                                            # (as the measured path does: first-collective set-up outside the clock)
+        nsteps = warmup + steps
+        if grouped:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(nsteps):
+            pred = _dry_forward(left + k, right)
+            sg.slot().copy_(pred[3])
+            sg.commit()
+        sg.flush()
+        if grouped:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        ok, npairs = None, 0
+        if rank == 0:
+            # the last gather must hold, for every rank, exactly that rank's shard of the unsharded result of the last step(s)
+            al, ar = make_batch(B * world, 16, 32, first_index=0)
+            al, ar = torch.from_numpy(al), torch.from_numpy(ar)
+            ok = True
+            for r in range(world):
+                got, nvalid = sg.gathered(r)
+                for j in range(nvalid):
+                    k = nsteps - nvalid + j
+                    want = _dry_forward(al + k, ar)[3][r * B:(r + 1) * B]
+                    ok = ok and bool(torch.equal(got[j * B:(j + 1) * B], want))
+                npairs += B
+        return {"gather_equals_unsharded": ok, "pairs_gathered": npairs, "gathers": sg.count, "wall_s": round(elapsed, 4)}
+
+    _inject("hang-collective", rank)
+    main_leg = leg(args.batch, args.steps, args.warmup)
+    c4 = leg(8, min(args.steps, 4), 1) if (world > 1 or args.config4) else None
+    ok = True
     if rank == 0:
-        # the last gather must hold, for every rank, exactly that rank's shard of the unsharded result of the last step(s)
-        al, ar = make_batch(B * world, 16, 32, first_index=0)
-        al, ar = torch.from_numpy(al), torch.from_numpy(ar)
-        ok = True
-        npairs = 0
-        for r in range(world):
-            got, nvalid = sg.gathered(r)
-            for j in range(nvalid):
-                k = nsteps - nvalid + j
-                want = _dry_forward(al + k, ar)[3][r * B:(r + 1) * B]
-                ok = ok and bool(torch.equal(got[j * B:(j + 1) * B], want))
-            npairs += B
-        print(json.dumps({"metric": "stereo pairs/sec @256x512 maxdisp=192 (stage-4)", "value": None, "unit": "pairs/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
-                          "gather_equals_unsharded": ok, "pairs_gathered": npairs, "gathers": sg.count,
-                          "wall_s": round(elapsed, 4),
-                          "note": "CPU/gloo plumbing check with a stand-in forward; no GPU, nothing measured"}), flush=True)
+        out = {"metric": "stereo pairs/sec @256x512 maxdisp=192 (stage-4)", "value": None, "unit": "pairs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, **main_leg,
+               "collective": {"backend": dist.get_backend() if grouped else None, "world": world},
+               "note": "CPU/gloo plumbing check with a stand-in forward; no GPU, nothing measured"}
+        if c4 is not None:
+            out["config4"] = {"workload": f"BASELINE config 4 (dry run): 8 pairs/GPU x {world} ranks = batch {8 * world}",
+                              "pairs_per_gpu": 8, "global_batch": 8 * world, "pairs_per_s": None, "ms_per_step": None,
+                              "all_ranks_slots_equal_unsharded": c4["gather_equals_unsharded"], **c4}
+        print(json.dumps(out), flush=True)
+        ok = bool(main_leg["gather_equals_unsharded"]) and (c4 is None or bool(c4["gather_equals_unsharded"]))
     if grouped:
         dist.destroy_process_group()
     if rank == 0 and not ok:
         raise SystemExit(1)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -188,10 +211,46 @@ def main():
                     help="N > 1 ranks of the REAL HIP path sharing cuda:0 (gloo; the gather carries device maps through the host: "
                          "RCCL refuses duplicate devices).  Exercises the N-rank code with two processes on one GPU; the ranks share "
                          "the chip, so nothing it prints is a throughput: value = null (tests/test_gpu_dist.py)")
-    args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(_self_launch(sys.argv[1:], args.gpus))
+    ap.add_argument("--collective", choices=("rccl", "gloo-host"), default="rccl",
+                    help="how the stage-4 maps reach rank 0: one RCCL gather over xGMI (default), or gloo through host memory -- "
+                         "the labelled fallback the supervisors start when the RCCL job fails (lwsnet_amd/launch.py)")
+    ap.add_argument("--job-timeout", type=float, default=600.0,
+                    help="seconds one attempt of the job may take before its workers are killed and the fallback (or the error "
+                         "line) takes over; also the in-process deadline of a plain single-GPU run")
+    ap.add_argument("--init-timeout", type=float, default=120.0,
+                    help="seconds for init_process_group (and, through torch's NCCL watchdog, every collective)")
+    ap.add_argument("--config4", action="store_true",
+                    help="also time BASELINE config 4's per-rank shape (8 pairs per GPU per step) and report it under `config4`; "
+                         "on by itself for N > 1")
+    ap.add_argument("--config4-steps", type=int, default=None, help="timed steps of the config-4 leg (default: 10..50 following --steps)")
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
+    from lwsnet_amd import launch
+    if os.environ.get("LWS_BENCH_WORKER") != "1":
+        if "WORLD_SIZE" in os.environ and "RANK" in os.environ:
+            # a torchrun rank (the driver's N > 1 launch, or the child of the branch below): supervise a fresh worker
+            if int(os.environ["WORLD_SIZE"]) != args.gpus:
+                raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch with torch.distributed.run for N > 1")
+            raise SystemExit(launch.supervise(os.path.abspath(__file__), sys.argv[1:], args))
+        if args.gpus > 1:
+            raise SystemExit(launch.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus, args.job_timeout, args.steps, args.warmup))
+        # plain single-GPU run, in this process: an in-process deadline instead of a supervisor
+        launch.arm_watchdog(args.job_timeout, lambda: print(launch.error_line(
+            1, args.steps, args.warmup, f"the run did not finish within --job-timeout {args.job_timeout:.0f} s"), flush=True))
+    try:
+        return worker(args)
+    except (Exception, SystemExit) as e:
+        # a worker that fails says why on stdout too, so that its supervisor can put the reason into the job's one line
+        if os.environ.get("LWS_BENCH_WORKER") == "1" and not (isinstance(e, SystemExit) and e.code in (0, None)):
+            print(launch.error_line(args.gpus, args.steps, args.warmup,
+                                    f"rank {os.environ.get('RANK', '0')}: {type(e).__name__}: {str(e)[:300]}"), flush=True)
+        raise
+
+
+def worker(args):
     from lwsnet_amd import _lib, dist as ldist
     from lwsnet_amd.models import LWSNet
     from lwsnet_amd.synth import make_batch
@@ -199,13 +258,19 @@ def main():
 
     global H, W
     H, W = [int(v) for v in args.size.split("x")]
-    rank, local_rank, world = ldist.init_from_env("gloo" if (args.dry_run_cpu or args.one_gpu) else None)
+    env_rank = int(os.environ.get("RANK", "0"))
+    _inject("hang", env_rank)
+    _inject("init-fail", env_rank)
+    through_host = args.dry_run_cpu or args.one_gpu or args.collective == "gloo-host"
+    rank, local_rank, world = ldist.init_from_env("gloo" if through_host else None, timeout_s=args.init_timeout)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
     if args.dry_run_cpu:
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the measured path)")
+    if not args.one_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"{torch.cuda.device_count()} HIP device(s) visible, the job has {world} ranks (one device per rank)")
     dev = ldist.local_device(local_rank, share_one_gpu=args.one_gpu)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
@@ -222,138 +287,181 @@ def main():
             m.set_option(o.split("=")[0], int(o.split("=")[1]))
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
     model = models[0]
-    B = args.batch
-    left_np, right_np = make_batch(B, H, W, first_index=rank * B)
-    left, right = torch.from_numpy(left_np).to(dev), torch.from_numpy(right_np).to(dev)
     lib = _lib.load()
-    for m in models:
-        _lib.check(lib.lws_reserve(m._h, B, H, W), "lws_reserve")
-
     grouped = dist.is_initialized()                      # torchrun launch (any world size, also 1): run the collective
-    # The ONE collective of the path: stage-4 maps -> rank 0 (north_star: "a single RCCL gather for
-    # the output disparities" of a batch).  The stage-4 maps of consecutive steps are written straight into the slots of a
-    # staging buffer (lws_forward's output pointer: no copy) and gathered together; how many pairs per rank one gather carries
-    # is a function of the world size (lwsnet_amd.dist.gather_policy: 8 pairs, 16 on eight ranks), chosen from the root-rank
-    # emulation of round 4 (profiles/r04/gather_root_emulation_d.txt).  Two staging buffers alternate, so
-    # the asynchronous gather of one overlaps the forwards that fill the other; every step's map is gathered inside the timed
-    # region (the tail is flushed before the clock stops).  NOTE (r04): in a world of ONE torch's NCCL gather is a tensor copy
-    # of the root's own shard -- no RCCL kernel runs -- so `collective.overhead_pct` of a one-rank run prices the staging, the
-    # stream hand-offs and that copy only.
-    G = ldist.gather_every(world, B, args.gather_pairs) if grouped else 1
-    sg = ldist.StagedGather(B, H, W, G, dev, multi_stream=S > 1) if grouped else None
+    KC_MID16, KC_CONV64 = 3, 11          # LWS_KC_CONV3D_MID16, LWS_KC_REF_CONV64 (include/lwsnet_hip.h)
     counter = [0]
 
-    def step():
-        i = counter[0] % S
-        counter[0] += 1
-        if S == 1:
-            pred = models[0](left, right, out=[None, None, None, sg.slot()] if grouped else None)
-            if grouped:
-                sg.commit()
-            return pred
-        with torch.cuda.stream(streams[i]):
-            pred = models[i](left, right, out=[None, None, None, sg.slot()] if grouped else None)
-            if grouped:
-                sg.commit()
-        return pred
+    def max_over_ranks(x):
+        if not grouped:
+            return float(x)
+        t = torch.tensor([x], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # spin-up (untimed, before the W warm-up steps): a short run started on an idle GPU measures the clock ramp, not the
-    # path -- the driver's --steps 20 --warmup 5 is 13 ms of GPU work and read 3.5 % below --steps 200 (r03).  Forwards for
-    # SPINUP_S seconds first; then W warm-up steps; then exactly K timed steps.
-    SPINUP_S = max(0.0, args.spinup)
-    t_spin = time.perf_counter()
-    n_spin, prev, settled = 0, None, False
-    # at least SPINUP_S seconds, then until two consecutive blocks of 25 forwards take the same time within 1 % (<= 2 s in all)
-    while SPINUP_S > 0 and (time.perf_counter() - t_spin < SPINUP_S or (not settled and time.perf_counter() - t_spin < 2.0)):
-        t1 = time.perf_counter()
-        for _ in range(25):
-            models[n_spin % S](left, right)
-            n_spin += 1
+    def run_leg(B, steps, warmup, spinup_s=0.0, before_timed=None, after_timed=None):
+        """W warm-up steps, then exactly K timed steps of B pairs per rank bracketed by barrier + synchronize on both sides; with a
+        process group every step's stage-4 map goes into the staged gather and the tail is flushed before the clock stops.  Then
+        the checks (rank 0's slot == its own last map; every other rank's slot == what rank 0 computes for that rank's pairs) and
+        the same K steps without the gather (what the ONE collective costs).  Times are the MAX over ranks."""
+        left_np, right_np = make_batch(B, H, W, first_index=rank * B)
+        left, right = torch.from_numpy(left_np).to(dev), torch.from_numpy(right_np).to(dev)
+        for m in models:
+            _lib.check(lib.lws_reserve(m._h, B, H, W), "lws_reserve")
+        # The ONE collective of the path: stage-4 maps -> rank 0 (SURVEY.md section 8e; north_star: "a single RCCL gather for
+        # the output disparities" of a batch).  The stage-4 maps of consecutive steps are written straight into the slots of a
+        # staging buffer (lws_forward's output pointer: no copy) and gathered together; how many pairs per rank one gather carries
+        # is a function of the world size (lwsnet_amd.dist.gather_policy: 8 pairs, 16 on eight ranks), chosen from the root-rank
+        # emulation of round 4 (profiles/r04/gather_root_emulation_d.txt; DESIGN.md section 5).  Two staging buffers alternate, so
+        # the asynchronous gather of one overlaps the forwards that fill the other; every step's map is gathered inside the timed
+        # region (the tail is flushed before the clock stops).  NOTE (r04): in a world of ONE torch's NCCL gather is a tensor copy
+        # of the root's own shard -- no RCCL kernel runs -- so `collective.overhead_pct` of a one-rank run prices the staging, the
+        # stream hand-offs and that copy only.
+        G = ldist.gather_every(world, B, args.gather_pairs) if grouped else 1
+        sg = ldist.StagedGather(B, H, W, G, dev, multi_stream=S > 1) if grouped else None
+
+        def step(gather=True):
+            i = counter[0] % S
+            counter[0] += 1
+            out = [None, None, None, sg.slot()] if (grouped and gather) else None
+            if S == 1:
+                pred = models[0](left, right, out=out)
+                if out is not None:
+                    sg.commit()
+                return pred
+            with torch.cuda.stream(streams[i]):
+                pred = models[i](left, right, out=out)
+                if out is not None:
+                    sg.commit()
+            return pred
+
+        # spin-up (untimed, before the W warm-up steps): a short run started on an idle GPU measures the clock ramp, not the
+        # path -- the driver's --steps 20 --warmup 5 is 13 ms of GPU work and read 3.5 % below --steps 200 (r03).  Forwards for
+        # spinup_s seconds first -- at least that long, then until two consecutive blocks of 25 forwards take the same time within
+        # 1 % (<= 2 s in all); then W warm-up steps; then exactly K timed steps.
+        t_spin = time.perf_counter()
+        n_spin, prev, settled = 0, None, False
+        while spinup_s > 0 and (time.perf_counter() - t_spin < spinup_s or (not settled and time.perf_counter() - t_spin < 2.0)):
+            t1 = time.perf_counter()
+            for _ in range(25):
+                models[n_spin % S](left, right)
+                n_spin += 1
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            settled = prev is not None and abs(dt - prev) <= 0.01 * prev
+            prev = dt
+        spun_s = time.perf_counter() - t_spin
+        if grouped:
+            _inject("hang-collective", rank)
+            sg.warm()                        # the communicator's one-time set-up must not land in the timed region
+        for _ in range(warmup):
+            step()
+        if grouped:
+            sg.flush()                       # ... nor a half-filled buffer of warm-up steps
+            sg.reset()
+        if before_timed:
+            before_timed()
+        if grouped:
+            sg.count = 0
+            dist.barrier()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        settled = prev is not None and abs(dt - prev) <= 0.01 * prev
-        prev = dt
-    spun_s = time.perf_counter() - t_spin
-    if grouped:
-        sg.warm()                        # the communicator's one-time set-up must not land in the timed region
-    for _ in range(args.warmup):
-        step()
-    if grouped:
-        sg.flush()                       # ... nor a half-filled buffer of warm-up steps
-        sg.reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pred = step()
+        if grouped:
+            sg.flush()                                       # tail gather + wait for everything in flight
+        torch.cuda.synchronize()
+        if grouped:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if after_timed:
+            after_timed()
+        gather_ok = all_ok = None
+        if grouped and rank == 0:                            # rank 0's part of the last gather holds this rank's last stage-4 map
+            mine, nvalid = sg.gathered(0)
+            gather_ok = bool(torch.equal(mine[(nvalid - 1) * B:nvalid * B], pred[3]))
+            # ... and every other rank's part must be what THIS rank computes for that rank's pairs (pure batch sharding: the
+            # sharded job equals the unsharded forward bit for bit, SURVEY.md section 8e) -- untimed, world forwards on rank 0
+            all_ok = gather_ok
+            for r in range(1, world):
+                ql, qr = make_batch(B, H, W, first_index=r * B)
+                want = models[0](torch.from_numpy(ql).to(dev), torch.from_numpy(qr).to(dev))[3]
+                theirs, nv = sg.gathered(r)
+                all_ok = all_ok and nv == nvalid and bool(torch.equal(theirs[(nv - 1) * B:nv * B], want))
+        # what the ONE collective of the path costs (SURVEY.md section 8e: "<= 3 %"): the same K steps again without the
+        # gather, same barriers, same clock -- measurable on one GPU under `torch.distributed.run --nproc-per-node 1`
+        t_plain = None
+        if grouped:
+            def plain_steps(n):
+                dist.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    step(gather=False)
+                torch.cuda.synchronize()
+                dist.barrier()
+                return time.perf_counter() - t1
+
+            plain_steps(min(warmup, 3))
+            t_plain = max_over_ranks(plain_steps(steps))
+        return {"B": B, "steps": steps, "elapsed": max_over_ranks(elapsed), "pred": pred, "left": left, "right": right,
+                "left_np": left_np, "right_np": right_np, "G": G, "gathers": sg.count if grouped else 0, "spun_s": spun_s,
+                "gather_ok": gather_ok, "all_ok": all_ok, "t_plain": t_plain}
+
     # inside the timed region only the dominant kernel class is bracketed by hipEvents (8 events per sampled step), and only
     # on every n-th step; the per-class breakdown comes from a separate, untimed pass below.  A kernel bracketed by its own
     # events keeps its successor from being queued behind it: ~3 us per timed launch at batch 1 unprofiled, 8 us under a
     # kernel trace (profiles/r04/timeline_b1_trace_only.txt shows such a forward), so timing EVERY step of a short run taxed
     # the headline by 3-4 % (VERDICT r2).  Every 8th step (round 4; every 4th before): the driver's --steps 20 gives 3 sampled
     # steps = 12 timed launches, the default 50 steps 7 = 28; the durations spread by +-1 %.
-    KC_MID16, KC_CONV64 = 3, 11          # LWS_KC_CONV3D_MID16, LWS_KC_REF_CONV64 (include/lwsnet_hip.h)
     sample_every = max(8, (args.steps // S) // 12)
-    for m in models:
-        _lib.check(lib.lws_profile_enable(m._h, 1 << KC_MID16), "lws_profile_enable")
-        _lib.check(lib.lws_profile_sample(m._h, sample_every), "lws_profile_sample")
-    if grouped:
-        sg.count = 0
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pred = step()
-    if grouped:
-        sg.flush()                                       # tail gather + wait for everything in flight
-    torch.cuda.synchronize()
-    if grouped:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    gather_ok = all_ok = None
-    if grouped and rank == 0:                            # rank 0's part of the last gather holds this rank's last stage-4 map
-        mine, nvalid = sg.gathered(0)
-        gather_ok = bool(torch.equal(mine[(nvalid - 1) * B:nvalid * B], pred[3]))
-        # ... and every other rank's part must be what THIS rank computes for that rank's pairs (pure batch sharding: the
-        # sharded job equals the unsharded forward bit for bit) -- untimed, world forwards on rank 0
-        all_ok = gather_ok
-        for r in range(1, world):
-            ql, qr = make_batch(B, H, W, first_index=r * B)
-            want = models[0](torch.from_numpy(ql).to(dev), torch.from_numpy(qr).to(dev))[3]
-            theirs, nv = sg.gathered(r)
-            all_ok = all_ok and nv == nvalid and bool(torch.equal(theirs[(nv - 1) * B:nv * B], want))
     tot = (ctypes.c_double * _lib.LWS_KC_COUNT)()
     cnt = (ctypes.c_int64 * _lib.LWS_KC_COUNT)()
-    mid_ms, mid_n = 0.0, 0
-    for m in models:
-        _lib.check(lib.lws_profile_read(m._h, tot, cnt), "lws_profile_read")
-        _lib.check(lib.lws_profile_enable(m._h, 0), "lws_profile_enable")
-        mid_ms += tot[KC_MID16]
-        mid_n += cnt[KC_MID16]
+    mid = {"ms": 0.0, "n": 0}
+
+    def arm_profiler():
+        for m in models:
+            _lib.check(lib.lws_profile_enable(m._h, 1 << KC_MID16), "lws_profile_enable")
+            _lib.check(lib.lws_profile_sample(m._h, sample_every), "lws_profile_sample")
+
+    def read_profiler():
+        for m in models:
+            _lib.check(lib.lws_profile_read(m._h, tot, cnt), "lws_profile_read")
+            _lib.check(lib.lws_profile_enable(m._h, 0), "lws_profile_enable")
+            mid["ms"] += tot[KC_MID16]
+            mid["n"] += cnt[KC_MID16]
+
+    B = args.batch
+    leg = run_leg(B, args.steps, args.warmup, spinup_s=max(0.0, args.spinup), before_timed=arm_profiler, after_timed=read_profiler)
+    elapsed, pred, left, right, left_np, right_np = leg["elapsed"], leg["pred"], leg["left"], leg["right"], leg["left_np"], leg["right_np"]
+    G, spun_s, gather_ok, all_ok = leg["G"], leg["spun_s"], leg["gather_ok"], leg["all_ok"]
+    mid_ms, mid_n = mid["ms"], mid["n"]
     mid_avg_us = 1e3 * mid_ms / max(mid_n, 1)
-    # what the ONE collective of the path costs ("<= 3 %"): the same K steps again without the
-    # gather, same barriers, same clock -- measurable on one GPU under `torch.distributed.run --nproc-per-node 1`
     collective_overhead = None
-    if grouped:
-        def step_plain():
-            i = counter[0] % S
-            counter[0] += 1
-            if S == 1:
-                return models[0](left, right)
-            with torch.cuda.stream(streams[i]):
-                return models[i](left, right)
-
-        def plain_steps(n):
-            dist.barrier()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(n):
-                step_plain()
-            torch.cuda.synchronize()
-            dist.barrier()
-            return time.perf_counter() - t1
-
-        plain_steps(min(args.warmup, 3))
-        t_plain = plain_steps(args.steps)
-        tt = torch.tensor([t_plain], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_plain = float(tt.item())
-        collective_overhead = {"ms_per_step_without_gather": round(1e3 * t_plain / args.steps, 4)}
+    if grouped and not through_host:
+        collective_overhead = {"ms_per_step_without_gather": round(1e3 * leg["t_plain"] / args.steps, 4)}
+    # BASELINE config 4's per-rank shape in the same job: 8 pairs per GPU per step (batch 8 N in all), its own warm-up, clock,
+    # staged gather, bit-equality check and gather price.  `value` above stays the 1-pair-per-GPU number.
+    config4 = None
+    if (world > 1 or args.config4) and (H, W, args.maxdisp0) == (256, 512, 24) and not args.feature_fp16:
+        k4 = args.config4_steps if args.config4_steps else max(10, min(args.steps, 50))
+        l4 = leg if B == 8 else run_leg(8, k4, max(3, min(args.warmup, 10)))
+        ms4 = 1e3 * l4["elapsed"] / l4["steps"]
+        config4 = {"workload": f"BASELINE config 4: {world} x MI355X batch-sharded, batch={8 * world} (8 pairs/GPU), 256x512 synthetic, "
+                               "maxdisplist=[24,5,5]",
+                   "pairs_per_gpu": 8, "global_batch": 8 * world, "steps": l4["steps"],
+                   "pairs_per_s": None if args.one_gpu else round(world * 8 * l4["steps"] / l4["elapsed"], 2), "ms_per_step": round(ms4, 4),
+                   "gather_every_steps": l4["G"], "gathers_in_timed_region": l4["gathers"],
+                   "rank0_slot_equals_local": l4["gather_ok"], "all_ranks_slots_equal_unsharded": l4["all_ok"]}
+        if grouped and l4["t_plain"] is not None and not through_host:
+            base4 = 1e3 * l4["t_plain"] / l4["steps"]
+            config4["ms_per_step_without_gather"] = round(base4, 4)
+            config4["gather_overhead_pct"] = round(100.0 * (ms4 - base4) / base4, 2)
+        if args.one_gpu:
+            config4["pairs_per_s_all_ranks_on_one_gpu"] = round(world * 8 * l4["steps"] / l4["elapsed"], 2)
+        if B != 8:                           # back to the main leg's shape for the untimed passes below
+            for m in models:
+                _lib.check(lib.lws_reserve(m._h, B, H, W), "lws_reserve")
     # untimed breakdown pass: every kernel class, 10 steps
     nb = 10
     KC_MID8 = 4
@@ -457,11 +565,6 @@ def main():
                                   "the float64 noise-floor tests); an opt-in numerics mode, never the headline"}
         finally:
             model.set_option("split_bf16", 0)
-    if grouped:
-        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     kernels = {}
     for kc in range(_lib.LWS_KC_COUNT):
         if cnt[kc]:
@@ -664,19 +767,24 @@ def main():
                    "pairs_per_gpu": B, "streams": S, "parallelism": f"batch-sharded x{world}, 1 RCCL gather of stage-4 per {G * B} pairs per rank" if grouped else "single GPU",
                    "weights": "seeded synthetic (seed 7, calibrated BN)", "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), **({"options": args.opt} if args.opt else {})},
         "roofline": roof, "secondary": secondary, "cpu_baseline": cpu, "latency_ms": latency, "pipelined": pipelined,
-        "split_bf16": split_bf16,
+        "split_bf16": split_bf16, "config4": config4,
         "hbm_kernels": hbm,
         "hot_path_kernel_ms_per_step": round(hot_ms, 4), "all_kernel_ms_per_step": round(all_ms, 4), "kernels": {k: {a: round(b, 2) for a, b in v.items()} for k, v in kernels.items()},
     }
     if grouped:
-        out["collective"] = {"backend": dist.get_backend(),
+        out["collective"] = {"backend": "gloo-through-host" if through_host else dist.get_backend(),
                              "op": f"async gather of stage-4 maps to rank 0, one per {G} step(s) = {G * B} pairs per rank per gather",
-                             "gather_every_steps": G, "gathers_in_timed_region": sg.count,
+                             "gather_every_steps": G, "gathers_in_timed_region": leg["gathers"],
                              "world": world, "rank0_slot_equals_local": gather_ok, "all_ranks_slots_equal_unsharded": all_ok}
         if args.one_gpu:
             out["shared_one_gpu"] = {"pairs_per_s_both_ranks_on_one_gpu": round(pairs / elapsed, 2),
                                      "note": f"{world} ranks of the HIP path sharing cuda:0 over gloo (device maps gathered through the "
                                              "host): a check of the N-rank code path, not a throughput -- value is null"}
+        if through_host:
+            # (the gloo form copies every shard through the host and blocks the issuing thread: its cost is not the collective's)
+            out["collective"]["overhead_pct"] = None
+            out["collective"]["note"] = ("device maps gathered over gloo through host memory: every gather synchronises the host, so "
+                                         "ms_per_step includes host round trips an RCCL gather does not have")
         if collective_overhead:
             base = collective_overhead["ms_per_step_without_gather"]
             collective_overhead["overhead_pct"] = round(100.0 * (out["ms_per_step"] - base) / base, 2)

@@ -63,11 +63,14 @@ def apply_channel_cap(world):
     return cap
 
 
-def init_from_env(backend=None, tune=True):
+def init_from_env(backend=None, tune=True, timeout_s=None):
     """Initialise the default process group from torchrun's environment.  Without that environment (plain
     `python bench.py`) this is a no-op; under torchrun a world of ONE is initialised too, so that a single GPU runs the
     same RCCL code path (communicator set-up, gather, barrier) the N-GPU job runs.  `tune`: apply gather_policy's channel
-    cap for this world size first (tools/gather_probe.py passes False to measure RCCL's own defaults)."""
+    cap for this world size first (tools/gather_probe.py passes False to measure RCCL's own defaults).
+    `timeout_s`: the process group's timeout (rendezvous, communicator set-up and -- through torch's NCCL watchdog -- every
+    collective): a rank that never arrives fails the others after this long instead of after torch's 10-minute default.
+    On the RCCL backend a rank whose LOCAL_RANK has no device fails at once with a message that says so."""
     rank, local_rank, world = env_rank()
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if launched and not dist.is_initialized():
@@ -76,7 +79,14 @@ def init_from_env(backend=None, tune=True):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
+        if timeout_s is not None:
+            from datetime import timedelta
+            kw["timeout"] = timedelta(seconds=float(timeout_s))
         if backend == "nccl":
+            have = torch.cuda.device_count()                  # (does not initialise HIP)
+            if local_rank >= have:
+                raise RuntimeError(f"rank {rank}: LOCAL_RANK {local_rank} has no HIP device ({have} visible, the job has "
+                                   f"{world} ranks): RCCL needs one device per rank")
             if tune:
                 apply_channel_cap(world)
             torch.cuda.set_device(local_rank)
@@ -153,7 +163,11 @@ def gather_pairs(local, counts=None, dst=0, group=None):
 def gather_async(local, bufs, dst=0, group=None):
     """The ONE collective of the path as bench.py issues it per step: equal shards, buffers pre-allocated on `dst`
     (`bufs`: list of world tensors there, None elsewhere), asynchronous -- RCCL runs it on its own stream behind this
-    step's kernels so it overlaps the next step.  Returns the work handle (wait() before reading `bufs`)."""
+    step's kernels so it overlaps the next step.  Returns the work handle (wait() before reading `bufs`).
+    On the gloo backend with device tensors (`_through_host`) the call is NOT asynchronous with respect to the device: the
+    shard is copied to the host here, which blocks the calling thread until the stream that produced it has drained, and
+    `wait()` copies the gathered shards back with blocking host-to-device copies.  That form exists to run the N-rank code
+    where RCCL cannot (ranks sharing one GPU; the labelled fallback of bench.py); what it costs is not the collective's price."""
     # `dst` of dist.gather is a GLOBAL rank: compare with the global rank, not the group-local one
     root = dist.get_rank() == dst
     if _through_host(local, group):
@@ -174,7 +188,8 @@ class StagedGather:
     With `multi_stream=True` steps may run on DIFFERENT streams (bench.py --streams N): `commit()` notes the stream that
     produced the slot and the gather is ordered behind every such stream (one event per stream per gather); `slot()` makes a
     stream wait, once, until the previous gather out of the buffer it hands out has completed (the gather used
-    to be ordered behind the last committing stream only)."""
+    to be ordered behind the last committing stream only).
+    On the gloo backend with device buffers `commit()` blocks the host whenever it issues a gather (see gather_async)."""
 
     def __init__(self, B, H, W, group, device, dtype=torch.float32, dst=0, multi_stream=False):
         self.B, self.group, self.dst = int(B), max(1, int(group)), dst

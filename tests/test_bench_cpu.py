@@ -9,13 +9,19 @@ import sys
 from conftest import ROOT
 
 
-def _run(*extra, steps="3"):
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-cpu", "--steps", steps, "--warmup", "1", *extra],
-                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-2000:]
+def _env(**more):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+           and not k.startswith("LWS_BENCH_")}
+    env.update(more)
+    return env
+
+
+def _run(*extra, steps="3", env=None, rc=0, dry=True, launcher=()):
+    cmd = [sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *(["--dry-run-cpu"] if dry else []), "--steps", steps, "--warmup", "1", *extra]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env or _env(), cwd=ROOT)
+    assert (p.returncode == 0) == (rc == 0), (p.returncode, p.stderr[-2000:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout
+    assert len(lines) == 1, p.stdout                    # exactly ONE JSON line, whatever happened
     return json.loads(lines[0])
 
 
@@ -44,6 +50,73 @@ def test_bench_eight_ranks_ragged_tail():
     d = _run("--gpus", "8", "--batch", "2", steps="4")
     assert d["n_gpus"] == 8 and d["dry_run"] is True and d["value"] is None
     assert d["gather_equals_unsharded"] is True and d["pairs_gathered"] == 16 and d["gathers"] == 3
+
+
+def test_bench_n_rank_job_reports_config4():
+    """under --gpus N > 1 the job also runs BASELINE config 4's per-rank shape (8 pairs per GPU per step,
+    batch 8 N) with its own gather check; `value` stays the --batch leg.  `--gpus 8 --dry-run-cpu` prints `config4`."""
+    d = _run("--gpus", "8")
+    c4 = d["config4"]
+    assert c4["pairs_per_gpu"] == 8 and c4["global_batch"] == 64 and c4["all_ranks_slots_equal_unsharded"] is True
+    assert c4["pairs_gathered"] == 64 and d["pairs_gathered"] == 8          # (the main leg: 1 pair per rank)
+    assert d["attempts"] == [{"collective": "gloo", "ok": True, "s": d["attempts"][0]["s"]}]
+    assert "config4" not in _run("--gpus", "1")
+
+
+def test_bench_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`: every torchrun rank is a supervisor that
+    starts its worker as a fresh child (lwsnet_amd/launch.py); rank 0 relays the one line."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    d = _run("--gpus", "2", "--batch", "2", launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                                                      "127.0.0.1", "--master-port", str(port)))
+    assert d["n_gpus"] == 2 and d["gather_equals_unsharded"] is True and d["config4"]["all_ranks_slots_equal_unsharded"] is True
+    assert [a["ok"] for a in d["attempts"]] == [True]
+
+
+def test_bench_init_failure_takes_the_labelled_fallback():
+    """A rank that fails at the rendezvous ends every rank's first attempt at once (failure flag in the supervisors' store);
+    ONE fallback job runs in fresh workers with the gather over gloo through the host and says so in collective.backend."""
+    d = _run("--gpus", "2", "--job-timeout", "60", "--init-timeout", "20", env=_env(LWS_BENCH_INJECT="init-fail:1"))
+    assert [a["ok"] for a in d["attempts"]] == [False, True] and d["attempts"][1]["collective"] == "gloo-host"
+    assert "injected init failure on rank 1" in d["attempts"][0]["reason"]
+    assert d["collective"]["backend"].startswith("gloo-through-host (") and "job failed" in d["collective"]["backend"]
+    assert d["gather_equals_unsharded"] is True and d["attempts"][0]["s"] < 30
+
+
+def test_bench_hung_rank_is_killed_by_the_watchdog():
+    """A rank that hangs before the rendezvous: the others' init_process_group times out (--init-timeout) or, failing that, the
+    supervisors' deadline (--job-timeout) kills the workers' process groups; the fallback then measures."""
+    d = _run("--gpus", "2", "--job-timeout", "12", "--init-timeout", "60", env=_env(LWS_BENCH_INJECT="hang:1"))
+    assert [a["ok"] for a in d["attempts"]] == [False, True]
+    assert "job timeout" in d["attempts"][0]["reason"] and 12 <= d["attempts"][0]["s"] < 25
+    assert d["collective"]["backend"].startswith("gloo-through-host (")
+
+
+def test_bench_hang_in_the_first_collective():
+    """A rank that never enters the first gather: the process group's timeout (--init-timeout applies to every collective)
+    fails the waiting ranks, the fallback takes over."""
+    d = _run("--gpus", "2", "--job-timeout", "60", "--init-timeout", "8", env=_env(LWS_BENCH_INJECT="hang-collective:1"))
+    assert [a["ok"] for a in d["attempts"]] == [False, True] and d["attempts"][0]["s"] < 40
+
+
+def test_bench_both_attempts_fail_prints_the_error_line():
+    """Nothing measurable: ONE JSON line with value null and the reasons, exit status != 0 -- never a hang, never silence."""
+    d = _run("--gpus", "2", "--job-timeout", "6", env=_env(LWS_BENCH_INJECT="hang:0", LWS_BENCH_INJECT_ATTEMPTS="all"), rc=1)
+    assert d["value"] is None and "job timeout" in d["error"] and [a["ok"] for a in d["attempts"]] == [False, False]
+
+
+def test_bench_too_few_devices_fails_fast():
+    """The measured (non-dry) job on a node with fewer devices than ranks: the supervisors see it with device_count (which does
+    not initialise HIP) and print the error line at once.  (This container has no GPU; on a GPU box the test needs < 2.)"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a node with fewer than 2 devices")
+    d = _run("--gpus", "2", dry=False, rc=4)
+    assert d["value"] is None and "HIP device(s) visible" in d["error"] and d["n_gpus"] == 2
 
 
 def test_gather_policy_is_a_function_of_world_size():

@@ -60,19 +60,25 @@ def test_two_ranks_on_one_gpu_sharded_forward_bitwise(hip_lib):
 
 
 def test_bench_two_ranks_on_one_gpu(hip_lib):
-    """`bench.py --gpus 2 --one-gpu --batch 8`: the driver's N > 1 launch shape (self-started torch.distributed.run, two
-    ranks, per-rank shard of seeded pairs, staged gather to rank 0, barrier-bracketed clock, MAX over ranks) on the HIP path
-    with both ranks sharing cuda:0.  The ranks share one chip, so the line carries no throughput: value is null."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-gpu", "--batch", "8", "--steps", "6", "--warmup", "2",
+    """`bench.py --gpus 2 --one-gpu`: the driver's N > 1 launch shape (self-started torch.distributed.run, two supervisors, two
+    fresh workers, per-rank shard of seeded pairs, staged gather to rank 0, barrier-bracketed clock, MAX over ranks) on the HIP
+    path with both ranks sharing cuda:0 -- the 1-pair-per-GPU leg that gives `value` AND the config-4 leg (8 pairs per GPU per
+    step).  The ranks share one chip, so the line carries no throughput: value is null."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-gpu", "--steps", "6", "--warmup", "2",
            "--no-cpu-baseline"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] is None and d["collective"]["backend"] == "gloo" and d["collective"]["world"] == 2
+    assert d["n_gpus"] == 2 and d["value"] is None and d["collective"]["backend"] == "gloo-through-host" and d["collective"]["world"] == 2
     assert d["collective"]["rank0_slot_equals_local"] is True and d["collective"]["all_ranks_slots_equal_unsharded"] is True
+    assert d["collective"]["overhead_pct"] is None                      # (gloo through the host: not the collective's price)
     assert d["shared_one_gpu"]["pairs_per_s_both_ranks_on_one_gpu"] > 0
+    c4 = d["config4"]
+    assert c4["pairs_per_gpu"] == 8 and c4["global_batch"] == 16 and c4["pairs_per_s"] is None and c4["ms_per_step"] > 0
+    assert c4["rank0_slot_equals_local"] is True and c4["all_ranks_slots_equal_unsharded"] is True
+    assert [a["ok"] for a in d["attempts"]] == [True]
     assert d["roofline"]["rank"] == 0 and d["roofline"]["traffic_measured_in_run"] is False
 
 
@@ -88,7 +94,26 @@ def test_bench_under_torchrun_world1(hip_lib):
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["collective"]["backend"] == "nccl"
-    assert d["collective"]["rank0_slot_equals_local"] is True
+    assert d["collective"]["rank0_slot_equals_local"] is True and [a["collective"] for a in d["attempts"]] == ["rccl"]
+
+
+def test_bench_rccl_failure_falls_back_to_gloo_through_host(hip_lib):
+    """The first attempt of a torchrun job fails at the rendezvous (injected): the supervisors start ONE fallback job in fresh
+    workers -- the real HIP path, the stage-4 gather over gloo through host memory, a device per rank (world 1 here) -- and the
+    line is measured and labelled `gloo-through-host (RCCL job failed: ...)`."""
+    env = _env()
+    env["LWS_BENCH_INJECT"] = "init-fail:0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3",
+           "--no-cpu-baseline", "--config4"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert [a["ok"] for a in d["attempts"]] == [False, True] and d["value"] > 0
+    assert d["collective"]["backend"].startswith("gloo-through-host (RCCL job failed: ")
+    assert d["collective"]["rank0_slot_equals_local"] is True and d["config4"]["rank0_slot_equals_local"] is True
 
 
 @pytest.mark.parametrize("batch,limit", [(8, 3.0), (1, 7.0)])
