@@ -435,6 +435,20 @@ def worker(args):
     leg = run_leg(B, args.steps, args.warmup, spinup_s=max(0.0, args.spinup), before_timed=arm_profiler, after_timed=read_profiler)
     elapsed, pred, left, right, left_np, right_np = leg["elapsed"], leg["pred"], leg["left"], leg["right"], leg["left_np"], leg["right_np"]
     G, spun_s, gather_ok, all_ok = leg["G"], leg["spun_s"], leg["gather_ok"], leg["all_ok"]
+    # the clock the dominant kernel held on this box / on every rank's GPU (lws_clock_probe: s_memtime against s_memrealtime
+    # inside k_conv3d_mid16, eight back-to-back launches right after the timed region, the last one stamped)
+    clock_ghz = None
+    if c3_first != 8:
+        ghz = ctypes.c_double(0.0)
+        _lib.check(lib.lws_clock_probe(model._h, B, H, W, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(ghz)),
+                   "lws_clock_probe")
+        clock_ghz = float(ghz.value)
+    clock_per_rank = None
+    if grouped and world > 1:
+        t = torch.tensor([clock_ghz or 0.0], device=red_dev, dtype=torch.float64)
+        allc = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allc, t)
+        clock_per_rank = [round(float(c.item()), 4) for c in allc]
     mid_ms, mid_n = mid["ms"], mid["n"]
     mid_avg_us = 1e3 * mid_ms / max(mid_n, 1)
     collective_overhead = None
@@ -534,9 +548,8 @@ def worker(args):
     # float32 operand, six exact cross products accumulated in float32).  An opt-in numerics mode: float32-level accuracy (tests/test_gpu_parity.py::
     # test_split_bf16_*), NOT bit-exact against the oracle chain, therefore never `value` and reported with its own dtype.
     split_bf16 = None
-    if (not grouped and S == 1 and not args.no_pipelined and model.get_option("mid16_form") == 0
-            and model.get_option("conv64_form") == 0 and model.get_option("mid8_form") == 1 and c3_first == 32):
-        model.set_option("split_bf16", 1)
+    if not grouped and S == 1 and not args.no_pipelined and model.get_option("split_bf16") == 0 and c3_first == 32:
+        model.set_option("split_bf16", 7)
         try:
             for _ in range(10):
                 px = model(left, right)
@@ -561,7 +574,7 @@ def worker(args):
                                    "refinement2[0], f32 accumulate",
                           "k_conv3d_mid16x_avg_launch_us": round(x_us, 2), "k_ref_conv64x_avg_launch_us": round(x64_us, 2),
                           "max_abs_vs_exact_per_stage": diff,
-                          "what": "option split_bf16 = 1 (mid16_form 1, mid8_form 2, conv64_form 1): not bit-exact against the oracle chain (float32-level accuracy, gated by "
+                          "what": "option split_bf16 = 7 (k_conv3d_mid16x, k_conv3d_mid8x, k_ref_conv64x): not bit-exact against the oracle chain (float32-level accuracy, gated by "
                                   "the float64 noise-floor tests); an opt-in numerics mode, never the headline"}
         finally:
             model.set_option("split_bf16", 0)
@@ -594,15 +607,18 @@ def worker(args):
     roof = None
     if mid:
         achieved = flop_per_launch / (mid["avg_us"] * 1e-6) / 1e12
-        # with --opt mid16_form=1 (experiments only) the class runs k_conv3d_mid16x: six bf16 MFMAs per float32 product,
+        # with --opt split_bf16=1 (experiments only) the class runs k_conv3d_mid16x: six bf16 MFMAs per float32 product,
         # so the ceiling for the same algorithmic FLOPs is the dense bf16 peak / 6
-        split = model.get_option("mid16_form") == 1
+        split = (model.get_option("split_bf16") & 1) != 0
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS
         roof = {"bound": "mfma", "kernel": "k_conv3d_mid16x<3,4> (split-bf16, NOT the oracle chain)" if split else "k_conv3d_mid16<32,3,4>",
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "peak_note": "bf16 dense peak / 6 cross products" if split else
-                             "nominal: 64 FLOP/clk/SIMD at 2.4 GHz; the in-kernel clock of this kernel reads 2.13 GHz "
-                             "(profiles/r04/stamps_inkernel_clock.txt), i.e. ~140 TF sustainable",
+                             "nominal: 64 FLOP/clk/SIMD at 2.4 GHz; see clock_ghz for the clock this kernel held in this run",
+                "clock_ghz": round(clock_ghz, 4) if clock_ghz else None,
+                **({"clock_ghz_per_rank": clock_per_rank} if clock_per_rank else {}),
+                "clock_note": "in-kernel clock of k_conv3d_mid16 (lws_clock_probe: d s_memtime / d s_memrealtime x 100 MHz, median of "
+                              "64 workgroups, the last of 8 back-to-back launches right after the timed region); peak is priced at 2.4 GHz",
                 "traffic": None, "flop_per_launch": flop_per_launch, "avg_launch_us": round(mid["avg_us"], 2),
                 "timed_launches": int(mid_n), "timed_every_nth_step": sample_every, "pairs_per_launch": pairs_per_launch}
     if pipelined is not None:
@@ -640,7 +656,7 @@ def worker(args):
                                "achieved": round(gf / avg * 1e3, 2), "frac": round(gf / avg * 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
         tot_us = sum(1e3 * v for v in mid8_each) / nb
         tot_gf = sum(2.0 * 27 * 64 * vox_s[si] * B * L3 for si in (1, 2)) / 1e9
-        secondary = {"kernel": "k_conv3d_mid8q (3x4x32 / 3x8x32 tiles by grid size)" if model.get_option("mid8_form") == 1 else "k_conv3d_mid8<3,4>",
+        secondary = {"kernel": "k_conv3d_mid8q (3x2x32 / 3x8x32 tiles by grid size)",
                      "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS,
                      "launches_per_step": len(mid8_each) // nb, "pairs_per_launch": ppl8, "us_per_step": round(tot_us, 2),
                      "achieved": round(tot_gf / tot_us * 1e3, 2), "frac": round(tot_gf / tot_us * 1e3 / PEAK_F32_MFMA_TFLOPS, 4), **per_stage,
@@ -747,7 +763,7 @@ def worker(args):
 
     pairs = world * B * args.steps
     dtype_name = "f32 (fp16-rounded features)" if args.feature_fp16 else "f32"
-    if model.get_option("mid16_form") == 1 or model.get_option("conv64_form") == 1 or model.get_option("mid8_form") == 2:
+    if model.get_option("split_bf16") != 0:
         # experiments only (--opt): the opt-in numerics mode, float32-level accuracy but not the oracle's bits
         dtype_name += " with split-bf16 MFMA operands (3 x bf16 per f32, f32 accumulate; not bit-exact against the oracle)"
     roof = _with_traffic(roof, B, H, W, args.maxdisp0, args.feature_fp16)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LWS_ABI_VERSION 7
+#define LWS_ABI_VERSION 8
 
 typedef enum {
     LWS_OK = 0,
@@ -46,6 +46,15 @@ typedef struct {
                                  fp16 (round-to-nearest-even) where the volume kernels read them; everything else,
                                  including the soft-argmin, stays float32.  Not part of the reference; cannot meet the
                                  1e-3 px tolerance, judged on 3-px error. */
+    int32_t interp_align_mode; /* 0 (default) / 1: which source index F.interpolate(mode="bilinear") uses in the reference's four
+                                 resizes (models/models.py:119,146,154,161; Paddle's align_corners=False, align_mode).
+                                 0 = half-pixel centres, src = ratio * (dst + 0.5) - 0.5 -- what the oracle bets Paddle 2.0rc0
+                                 does; 1 = src = ratio * dst, the Paddle 1.x / 2.0-beta default.  The
+                                 reference cannot be run here (no Paddle wheel), so the bet is a switch, not a constant: every
+                                 resize of the path takes its taps from one helper (src_index, lws_device_math.h), the C oracle
+                                 has the same switch (lwso_set_align_mode) and both values are bit-exact against it
+                                 (tests/test_gpu_parity.py::test_interp_align_mode_*).  The per-op entry points without a
+                                 handle (lws_volume_l1_warp, lws_upsample_add) compute mode 0.  (ABI v8) */
 } lws_config;
 
 typedef struct lws_ctx *lws_handle;
@@ -131,72 +140,44 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
 
 /* Launch-plan options of lws_forward / lws_disparity_stages.  They change which kernels / streams carry the work, never
  * the arithmetic: every setting returns the same bits (tests/test_gpu_parity.py::test_forward_schedule_options) -- except
- * the opt-in numerics mode "split_bf16" = 1 and the three settings it stands for ("mid16_form" = 1, "mid8_form" = 2,
- * "conv64_form" = 1; see below).
- *   "left_at"        -1 (default: 2), 0 = refinement1_left starts with the forward, 2 = beside stages 2-3
- *   "split_heads"    -1 (default: off), 0/1 = right-image feature head on its own stream
- *   "fuse_shift"     1 (default) = stage-1 volume built inside the first Conv3D launch
- *   "fuse_first"     1 (default) = refinement1_disp's 1 -> 32 convolution inside its first depthwise block
+ * the opt-in numerics mode "split_bf16".  (ABI v8 removed the options two rounds of sweeps had retired: left_at, split_heads,
+ * fuse_shift, conv3d_order, mid8_tile, mid8_balance, fork_ext, tail_at, and folded mid8_form / mid16_form / conv64_form into
+ * "split_bf16"; what was measured against what is in profiles/NOTES.md.)
+ *   "fuse_first"     bit mask, 3 (default): bit 0 = refinement1_disp's 1 -> 32 convolution, bit 1 = refinement1_left's 3 -> 32
+ *                    convolution inside their first depthwise blocks (one launch and one 32-channel map less each)
  *   "defer_upsample" 1 (default) = at batches <= 2 the consumers evaluate the stage-2/3 maps
- *   "mid8_form"      the 8 -> 8 Conv3D layers (stages 2, 3): 1 (default) = v_mfma_f32_4x4x1_16B_f32 with the A block
- *                    broadcast (k_conv3d_mid8q: 4 couts x 64 voxels per instruction, no padding), 0 = v_mfma_f32_16x16x4_f32
- *                    with rows = (x parity, cout) (k_conv3d_mid8: 25 % of every instruction is structural zero padding;
- *                    measured r03 10-25 % slower); k_conv3d_mid8q picks 3 x 8 x 32 or 3 x 4 x 32 voxel tiles by grid size;
- *                    2 = k_conv3d_mid8x, split-bf16 MFMA (NOT bit-exact, see "split_bf16"; samples under 256 tiles stay on
- *                    k_conv3d_mid8q)
- *   "mid16_form"     0 (default) = the 32 -> 32 Conv3D layers on the f32-input MFMA, the oracle's fma chain bit for bit;
- *                    1 = k_conv3d_mid16x: split-bf16 MFMA (each float32 operand as three bf16 values, six exact cross
- *                    products accumulated in float32): ~2.5x the MFMA issue rate at float32-level accuracy, but NOT
- *                    bit-exact -- an opt-in numerics mode, never what bench.py's headline measures
- *   "conv64_form"    0 (default) = refinement2[0] (64 -> 32, dilation 8) on the f32-input MFMA, bit-exact;
- *                    1 = k_ref_conv64x, the same split-bf16 scheme (NOT bit-exact)
- *   "split_bf16"     0 (default) / 1: one switch for the three above (sets mid16_form = conv64_form = 1, mid8_form = 2, or
- *                    back to 0 / 0 / 1; reads 1 when all three are on).  Float32-level accuracy -- gated against the float64
- *                    oracle by tests/test_gpu_parity.py::test_split_bf16_* -- for +20-26 % pairs/s (r03: 2,418 vs 2,000 at
- *                    batch 1, 3,707 vs 2,950 at batch 8, 256x512), but not the oracle's bits: use it where the reference's own
- *                    float32 noise floor is the requirement, not reproducibility against the oracle
- *   "conv3d_order"   tile order of the Conv3D kernels inside an XCD's run: 1 (default) = d fastest (the tiles that share
- *                    halo planes are co-resident: re-reads hit that XCD's L2), 0 = x fastest
- *   "side_streams"   1 (default) = refinement1_left and the feature-extractor tail run on handle-owned side streams;
+ *   "split_bf16"     0 (default) or a bit mask: 1 = the 32 -> 32 Conv3D layers (k_conv3d_mid16x), 2 = the 8 -> 8 Conv3D layers
+ *                    of stages 2, 3 (k_conv3d_mid8x; samples under 256 tiles stay on the exact kernel), 4 = refinement2[0]
+ *                    (k_ref_conv64x); 7 = all of them.  Split-bf16 MFMA: each float32 operand as three bf16 values, six exact
+ *                    cross products accumulated in float32 -- ~2.5x the MFMA issue rate at float32-level accuracy, gated
+ *                    against the float64 oracle by tests/test_gpu_parity.py::test_split_bf16_*, but NOT the oracle's bits: an
+ *                    opt-in numerics mode, never what bench.py's headline measures
+ *   "side_streams"   1 (default) = refinement1_left and the feature-extractor tail run on a handle-owned side stream;
  *                    0 = the whole forward on the caller's stream, no forks / joins (what lws_pool workers use)
  *   "ref_chunk_mb"   72 (default): the refinement runs in chunks of pairs whose [b,H,W,32] maps are at most this many MB
  *                    each, so that a chunk's maps stay in the 256 MiB Infinity Cache between layers (batch 8 at 256x512:
  *                    two chunks of 4; 368x1232: one pair per chunk); 0 = one chunk
  *   "ref_pipe"       -1 (default: on from four chunks up), 0 / 1: consecutive refinement chunks alternate between the caller's
  *                    stream and the handle's side stream, one chunk's memory-bound blocks beside the other's 64 -> 32 convolution
- *                    (r03: 810 -> 833 pairs/s at 8 x 368x1232; two chunks only, 8 x 256x512: 2,958 -> 2,930, hence the default)
- *   "mid8_balance"   1 (default) / 0: on grids of at most four small tiles per CU k_conv3d_mid8q takes the small tile whenever
- *                    that is the shorter schedule of the fullest CU (one 256x512 pair at stage 3: 768 small 3 x 4 x 32-voxel units
- *                    = 3 per CU instead of 384 large tiles = 2 on half of the CUs); lws_pool workers run with 0.  (Round 4 also
- *                    capped the residency through the LDS request; since round 5 the small tile is 3 x 2 x 32 and uncapped --
- *                    "mid8_tile" = 3 brings the capped 3 x 4 x 32 form back)
- *   "mid8_tile"      0 (default: by grid size -- 3 x 8 x 32 voxels once >= 192 such tiles exist and they balance, else 3 x 2 x 32,
- *                    round 5) / 1..4 force k_conv3d_mid8q's tile: 3x2, 1x4, 3x4 (with "mid8_balance"'s residency cap), 3x8
- *                    rows x 32; t2 + 8 t3 addresses stages 2 and 3 separately
- *   "fork_ext"       1 (default) / 0: the two forks of lws_forward (side stream started behind the feature head / behind stage 1's
- *                    Conv3D stack) use an event bound to the producer kernel's own completion signal instead of a
- *                    hipEventRecord marker on the caller's stream (round 5: 1.3 instead of 2.6 us per fork on the chain)
- *   "fork2_after"    -1 (default: behind the last middle layer) / 0 / k: where
- *                    the second fork of lws_forward sits -- behind stage 1's last Conv3D layer (0: rounds 1-4) or behind its k-th
- *                    middle layer, so that the side branch starts beside the end of the stage-1 stack (round 5: +0.5 % at batch
- *                    1; one layer earlier another 0.3-0.6 % from batch 2 up, at the dominant kernel's expense)
- *   "tail_at"        -1 (default: 1 -- measured round 5: 0 costs the stage-1 MFMA kernels more than the join it saves, 2 makes
- *                    stage 2 wait for its 1/4 map at batch 1) / 0 / 1 / 2 (2: conv5 too starts at the second fork -- no first fork): the feature-extractor tail conv6 + classif1 (-> the 1/2
- *                    map of stage 3) is started with conv5 at the first fork (0: ONE join on the caller's stream serves stages 2
- *                    and 3; a join costs ~5 us of a batch-1 chain) or after stage 1's Conv3D stack (1: beside stage 2)
+ *   "fork2_after"    -1 (default: behind the last middle layer) / 0 / k: where the second fork of lws_forward sits -- behind
+ *                    stage 1's last Conv3D layer (0) or behind its k-th middle layer, so that the side branch starts beside the
+ *                    end of the stage-1 stack
  *   "warp_form"      residual volumes of stages 2 and 3: 1 (default) = k_volume_l1_warp stages the right-feature window of a
  *                    64-pixel row segment (all channels, zero-filled outside the image) in LDS and computes the 2m - 1
  *                    hypotheses from it; 0 = every tap gathered from global memory (the form a tile falls back to when its
  *                    flow range needs more than 160 window columns)
  *   "fuse_last1"     1 (default) / 0: batches <= 2 (with "defer_upsample"): stage 1's last Conv3D layer and the soft-argmin run in
  *                    one launch (24 x 2 x 4 tiles spanning D) and NO launch materialises pred1: stage 2's warp kernel evaluates
- *                    the taps it needs from the 1/8 map, stage 3's warp kernel writes pred1 beside pred2 (round 5: one launch
- *                    less on the batch-1 chain); 0 = k_conv3d_last + k_softargmin_upsample
+ *                    the taps it needs from the 1/8 map, stage 3's warp kernel writes pred1 beside pred2;
+ *                    0 = k_conv3d_last + k_softargmin_upsample
  *   "fuse_ref_last"  -1 (default: batch 1 only) / 0 / 1: refinement2's last depthwise-separable block (dilation 1), the 32 -> 1
  *                    convolution and "+ pred3" in one launch (k_ref_dws_last: the block recomputed on the one-pixel ring the
- *                    convolution needs; round 5) instead of k_ref_dws + k_ref_last
+ *                    convolution needs) instead of k_ref_dws + k_ref_last
  *   "device"         the HIP device the handle belongs to; settable only before lws_finalize / lws_reserve allocate
- * Unknown names and out-of-range values return LWS_ERR_INVALID. */
+ * Unknown names and out-of-range values return LWS_ERR_INVALID.
+ * hipGraph capture: lws_reserve first (nothing may allocate while capturing), then capture lws_forward on a non-default
+ * stream; the library sees the capture (hipStreamIsCapturing), records its forks as capture-time events instead of binding
+ * them to kernel completion signals, and times nothing (tests/test_gpu_parity.py::test_graph_capture_replays_the_forward). */
 int lws_set_option(lws_handle h, const char *name, int value);
 int lws_get_option(lws_handle h, const char *name, int *value);
 
@@ -207,7 +188,7 @@ typedef enum {
     LWS_KC_VOLUME_WARP = 1,    /* k_volume_l1_warp                       */
     LWS_KC_CONV3D_FIRST = 2,   /* k_conv3d_first  (1 -> C3)              */
     LWS_KC_CONV3D_MID16 = 3,   /* k_conv3d_mid16 / k_conv3d_mid16x (C3 -> C3, C3 % 16 == 0, MFMA) */
-    LWS_KC_CONV3D_MID8 = 4,    /* k_conv3d_mid8q / k_conv3d_mid8 (8 -> 8, fp32 MFMA) */
+    LWS_KC_CONV3D_MID8 = 4,    /* k_conv3d_mid8q / k_conv3d_mid8x (8 -> 8, MFMA) */
     LWS_KC_CONV3D_LAST = 5,    /* k_conv3d_last   (C3 -> 1, + skip)      */
     LWS_KC_SOFTARGMIN = 6,     /* k_softargmin                           */
     LWS_KC_UPSAMPLE = 7,       /* k_upsample_add                         */
@@ -235,6 +216,13 @@ int lws_profile_read(lws_handle h, double *total_ms, int64_t *launches);
  * launches of k_conv3d_mid8 with it). */
 int lws_profile_read_class(lws_handle h, int kernel_class, float *ms_out, int capacity, int *count);
 const char *lws_kernel_class_name(int kernel_class);
+/* The clock the dominant kernel really runs at (ABI v8): launches the stage-1 32 -> 32 Conv3D layer (k_conv3d_mid16) of a
+ * B x H x W forward eight times back to back on `stream` -- outside any timed region; its inputs are whatever the workspace
+ * holds -- and in the last launch the first 64 workgroups stamp s_memtime (shader clock) and s_memrealtime (100 MHz) at
+ * their first and last instruction.  *ghz = median over those workgroups of d s_memtime / d s_memrealtime x 100 MHz.
+ * Synchronises `stream`.  bench.py reports it as roofline.clock_ghz (per rank for N > 1): a box that holds a lower clock
+ * shows up here, not as an unexplained slower step.  LWS_ERR_STATE when stage 1's C3 is 8 (no k_conv3d_mid16 in the model). */
+int lws_clock_probe(lws_handle h, int B, int H, int W, void *stream, double *ghz);
 
 /* ---- several forwards in flight (no counterpart in the reference: inference.py:105-109 is one thread, one stream) ---- */
 /* A second handle for the same model on the same device: shares src's (read-only) parameter slab, owns its workspace,

@@ -19,7 +19,7 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 class LwsConfig(ctypes.Structure):
     _fields_ = [("maxdisplist", ctypes.c_int32 * 3), ("layers_3d", ctypes.c_int32),
                 ("channels_3d", ctypes.c_int32), ("growth_rate", ctypes.c_int32 * 3),
-                ("feature_fp16", ctypes.c_int32)]
+                ("feature_fp16", ctypes.c_int32), ("interp_align_mode", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); exactly the functions include/lwsnet_hip.h declares
@@ -49,6 +49,7 @@ PROTOTYPES = {
     "lws_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), c_int64_p]),
     "lws_profile_read_class": (_i, [_vp, _i, c_float_p, _i, ctypes.POINTER(_i)]),
     "lws_kernel_class_name": (ctypes.c_char_p, [_i]),
+    "lws_clock_probe": (_i, [_vp, _i, _i, _i, _vp, ctypes.POINTER(ctypes.c_double)]),
     "lws_clone": (_i, [_vp, ctypes.POINTER(_vp)]),
     "lws_pool_create": (_i, [_vp, _i, _i, ctypes.POINTER(_vp)]),
     "lws_pool_destroy": (_i, [_vp]),
@@ -92,7 +93,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lws_abi_version() != 7:
+    if lib.lws_abi_version() != 8:
         raise RuntimeError("liblwsnet_hip.so ABI version mismatch; rebuild the extension")
     _lib = lib
     return lib

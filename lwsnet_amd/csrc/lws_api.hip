@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <functional>
 #include <stdlib.h>
 
@@ -105,6 +106,9 @@ struct WsLayout {
 // Feature-map sizes: the stem convolution (submodules.py:118-125: k3 s2 dil2 pad2) gives ceil(H/2); the hourglass halves
 // twice more (check_size guarantees ceil(H/2) % 4 == 0).  H = 8k-1 is therefore as legal as H = 8k.
 static inline int half_up(int v) { return (v + 1) / 2; }
+
+// src_index's offset for every resize of the path (lws_device_math.h): lws_config.interp_align_mode
+static inline float ioff_of(const lws_ctx *h) { return h->cfg.interp_align_mode == 1 ? 0.0f : 0.5f; }
 
 static bool stage_dims(const lws_ctx *h, int s, int H, int W, int &D, int &hh, int &ww)
 {
@@ -226,11 +230,12 @@ static void prof_clear(lws_ctx *h)
 
 // low != nullptr: the soft-argmin is wanted too; *fused tells the caller whether it was done here
 // last_stop (optional): an event that must be complete once the stack's last kernel is (stop_after = 0) or once its
-// stop_after-th middle layer is -- bound to that kernel's completion signal where the launcher supports it (stop_event_arm,
-// lws_common.h), recorded behind it otherwise
+// stop_after-th middle layer is -- bound to that kernel's completion signal (stop_ext, StopArm in lws_common.h) or recorded
+// behind it
 static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost_out, float *act_a, float *act_b,
                         int B, int D, int hh, int ww, hipStream_t st, float *low = nullptr, float start = 0.f,
-                        bool *fused = nullptr, bool first_done = false, hipEvent_t last_stop = nullptr, int stop_after = 0)
+                        bool *fused = nullptr, bool first_done = false, hipEvent_t last_stop = nullptr, int stop_after = 0,
+                        bool stop_ext = false)
 {
     const Stage3d &s = h->stage[stage];
     int rc = LWS_OK;
@@ -241,7 +246,7 @@ static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost
     if (rc) return rc;
     float *src = act_a, *dst = act_b;
     for (int j = 1; j <= h->cfg.layers_3d; ++j) {
-        if (last_stop != nullptr && j == stop_after) stop_event_arm(last_stop);
+        StopArm stop(j == stop_after ? last_stop : nullptr, st, stop_ext);
         if (s.c3 != 8 && ((h->prof_mask >> LWS_KC_CONV3D_MID16) & 1u) && h->prof.size() < kMaxProfRecords) {
             // dominant kernel: timed by its own begin / end timestamps, not by events around the launch
             lws_prof_rec rec;
@@ -254,13 +259,13 @@ static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost
             ProfScope p(h, s.c3 == 8 ? LWS_KC_CONV3D_MID8 : LWS_KC_CONV3D_MID16, st);
             rc = launch_conv3d_mid(s, j, src, dst, B, D, hh, ww, st);
         }
+        LWS_HIP(stop.finish(rc));
         if (rc) return rc;
         std::swap(src, dst);
-        if (last_stop != nullptr && j == stop_after && stop_event_take() != nullptr) LWS_HIP(hipEventRecord(last_stop, st));
     }
     {
         ProfScope p(h, LWS_KC_CONV3D_LAST, st);
-        if (last_stop != nullptr && stop_after == 0) stop_event_arm(last_stop);
+        StopArm stop(stop_after == 0 ? last_stop : nullptr, st, stop_ext);
         if (low != nullptr && conv3d_last_can_fuse(s, D)) {
             *fused = true;
             rc = launch_conv3d_last_softargmin(s, src, cost_in, nullptr, low, start, B, D, hh, ww, st);
@@ -268,8 +273,8 @@ static int conv3d_stack(lws_ctx *h, int stage, const float *cost_in, float *cost
             if (fused) *fused = false;
             rc = launch_conv3d_last(s, src, cost_in, cost_out, B, D, hh, ww, st);
         }
+        LWS_HIP(stop.finish(rc));
     }
-    if (stop_after == 0 && stop_event_take() != nullptr && rc == LWS_OK) LWS_HIP(hipEventRecord(last_stop, st));   // the launcher did not bind it
     return rc;
 }
 
@@ -436,30 +441,22 @@ static void bind_net2d(lws_ctx *h, const Net2dOffsets &o)
     n.r2_last = h->params + o.r2_last;
 }
 
-// right-image feature head on its own stream?  Auto = never: measured r03 (bench.py, left_at = 2): 2,793 vs 2,784 pairs/s at
-// batch 4, 2,896 vs 2,879 at batch 8, 799 vs 800 at 8 x 368x1232 without it (r01 had +4 % at batch 8 WITH it, while
-// refinement1_left still ran beside the feature head); -11 % at batch 1.  lws_set_option("split_heads", 1) forces it.
-static bool split_heads(const lws_ctx *h, int B)
-{
-    (void)B;
-    return h->opt.split_heads > 0;
-}
-
-// feature_extraction.forward (submodules.py:176-188) on N images; first layer may read two separate inputs
 static int feature_tail(lws_ctx *h, int N, int H, int W, const WsLayout &L, float *f8, float *f4, float *f2,
                         hipStream_t st, hipEvent_t *ev, int part = 3);
 
-// If tail != nullptr only the layers up to the 1/8 map run here (stage 1 needs nothing else); the caller runs
-// feature_tail (conv5, conv6, classif1 -> f4, f2) on the `tail` stream later, overlapped with the volume stages.
-// fork_ev (optional, single-head plan only): complete once f8 / pre are -- bound to the last head kernel (stop_event_arm)
+// feature_extraction.forward (submodules.py:176-188) on N = nA + nB images read from two tensors (left batch, right batch) as
+// ONE batch.  head_only: only the layers up to the 1/8 map run here (stage 1 needs nothing else); the caller runs feature_tail
+// (conv5, conv6, classif1 -> f4, f2) on a side stream later, beside the volume stages.
+// fork_ev (optional): complete once f8 / pre are -- bound to the last head kernel's completion signal (fork_ext) or recorded
 static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, int nA, int nB, int H, int W,
                               const WsLayout &L, float *f8, float *f4, float *f2, hipStream_t st,
-                              hipStream_t tail = nullptr, hipEvent_t *ev = nullptr, hipEvent_t fork_ev = nullptr)
+                              bool head_only = false, hipEvent_t fork_ev = nullptr, bool fork_ext = false)
 {
     const Net2d &n = h->net2d;
-    const int N = nA + nB, H2 = half_up(H), W2 = half_up(W), H4 = H2 / 2, W4 = W2 / 2, H8 = H2 / 4, W8 = W2 / 4;
+    const int N = nA + nB, H2 = half_up(H), W2 = half_up(W), H4 = H2 / 2, W4 = W2 / 2;
     float *ws = h->ws;
     float *o = ws + L.fe_o, *o2 = ws + L.fe_o2, *pre = ws + L.fe_pre;
+    const float *img2 = nB > 0 ? imgB : nullptr;
     int rc;
 #define LWS_FE(call)                                   \
     {                                                  \
@@ -467,38 +464,20 @@ static int feature_extraction(lws_ctx *h, const float *imgA, const float *imgB, 
         rc = (call);                                   \
     }                                                  \
     if (rc) return rc;
-    // layers up to the 1/8 map (dres0, dres1, hourglass conv1..conv4) for `cnt` images starting at batch index i0 on
-    // stream s; images [0, n1) are read from img, the rest from img2.  Consecutive layers run pairwise in one launch
-    // (k_conv2d_pair / k_conv2d_pair_mfma, the same fma chains as one kernel per layer).
-    auto head = [&](hipStream_t s, const float *img, const float *img2, int n1, int i0, int cnt) -> int {
-        hipStream_t st = s;   // (the profiling macro names the stream `st`)
-        const size_t q2 = (size_t)i0 * H2 * W2, q4 = (size_t)i0 * H4 * W4, q8 = (size_t)i0 * H8 * W8;
-        LWS_FE(launch_conv2d_pair(n.fe[0], n.fe[1], img, nullptr, o + 8 * q2, cnt, H, W, st, img2, n1));         // dres0
-        LWS_FE(launch_conv2d_pair(n.fe[2], n.fe[3], o + 8 * q2, o + 8 * q2, o2 + 8 * q2, cnt, H2, W2, st));      // dres1 + o (:179)
-        LWS_FE(launch_conv2d_pair(n.fe[4], n.fe[5], o2 + 8 * q2, nullptr, pre + 16 * q4, cnt, H2, W2, st));      // conv1, conv2 -> pre
-        if (fork_ev != nullptr) stop_event_arm(fork_ev);
-        LWS_FE(launch_conv2d_pair(n.fe[6], n.fe[7], pre + 16 * q4, nullptr, f8 + 16 * q8, cnt, H4, W4, st));     // conv3, conv4 -> f8
-        if (stop_event_take() != nullptr) LWS_HIP(hipEventRecord(fork_ev, st));                                  // not bound by the launcher
-        return LWS_OK;
-    };
-    if (tail != nullptr && tail != st && split_heads(h, nB) && h->side2 != nullptr && fork_ev == nullptr) {
-        // left and right images are independent up to the cost volume: for batches >= 4 pairs the right images'
-        // layers run on a second side stream and join before f8 is consumed (measured r01: +4 % at B = 8, but
-        // -11 % at B = 1, where the two half-size launches only add dispatch overhead: there they stay batched)
-        LWS_HIP(hipStreamWaitEvent(h->side2, h->ev_fork, 0));
-        rc = head(h->side2, imgB, nullptr, nB, nA, nB);
-        if (rc) return rc;
-        LWS_HIP(hipEventRecord(h->ev_right, h->side2));
-        rc = head(st, imgA, nullptr, nA, 0, nA);
-        if (rc) return rc;
-        LWS_HIP(hipStreamWaitEvent(st, h->ev_right, 0));
-    } else {
-        rc = head(st, imgA, nB > 0 ? imgB : nullptr, nA, 0, N);   // one batch over all N images (two input tensors)
-        if (rc) return rc;
+    // dres0, dres1, hourglass conv1..conv4: consecutive layers run pairwise in one launch (k_conv2d_pair /
+    // k_conv2d_pair_mfma, the same fma chains as one kernel per layer)
+    LWS_FE(launch_conv2d_pair(n.fe[0], n.fe[1], imgA, nullptr, o, N, H, W, st, img2, nA));          // dres0
+    LWS_FE(launch_conv2d_pair(n.fe[2], n.fe[3], o, o, o2, N, H2, W2, st));                           // dres1 + o (:179)
+    LWS_FE(launch_conv2d_pair(n.fe[4], n.fe[5], o2, nullptr, pre, N, H2, W2, st));                   // conv1, conv2 -> pre
+    {
+        StopArm stop(fork_ev, st, fork_ext);
+        ProfScope p_(h, LWS_KC_FEATURE2D, st);
+        rc = launch_conv2d_pair(n.fe[6], n.fe[7], pre, nullptr, f8, N, H4, W4, st);                  // conv3, conv4 -> f8
+        LWS_HIP(stop.finish(rc));
     }
+    if (rc) return rc;
 #undef LWS_FE
-    if (tail != nullptr) return LWS_OK;
-    (void)ev;
+    if (head_only) return LWS_OK;
     return feature_tail(h, N, H, W, L, f8, f4, f2, st, nullptr);
 }
 
@@ -544,8 +523,7 @@ static int feature_tail(lws_ctx *h, int N, int H, int W, const WsLayout &L, floa
 // another.  A chunk of pairs runs its whole layer chain before the next chunk starts, sized so that one map of the chunk is
 // at most `ref_chunk_mb` MB: the three maps a block chain touches then stay in the 256 MiB Infinity Cache between a block's
 // write and the next block's read (MI355X_MICROARCH.md: a table stays resident while it plus everything moved between two
-// uses fits in ~256 MiB).  Measured r03 (tools/rbench.py, per pair): k_ref_dws 8.25 us at batch 8 against 7.5 us at batch 4.
-// 0 = one chunk.  Pairs are independent, so chunking cannot change a bit.
+// uses fits in ~256 MiB).  0 = one chunk.  Pairs are independent, so chunking cannot change a bit.
 static int refine_chunk(const lws_ctx *h, int B, int H, int W)
 {
     if (h->opt.ref_chunk_mb <= 0) return B;
@@ -573,8 +551,14 @@ static int refine_left_chunk(lws_ctx *h, const float *left, int B, int H, int W,
     // the result keeps its slice of r_a; the scratch map r_c is the SAME memory for every chunk (it stays cache-resident)
     float *ra = h->ws + L.r_a + (size_t)b0 * H * W * 32, *rc_ = h->ws + L.r_c;
     int rc;
-    LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(left, 3, n.r1_first[0], ra, B, H, W, st));
-    LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][0], ra, rc_, B, H, W, st));
+    if ((h->opt.fuse_first & 2) && ref_first_dws_can_fuse(n.r1[0][0], 3)) {
+        // the 3 -> 32 convolution is recomputed inside the first block's staging: one launch less, and the 32-channel map
+        // it would write (and the block read back) never exists
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[0][0], left, 3, n.r1_first[0], rc_, B, H, W, st));
+    } else {
+        LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(left, 3, n.r1_first[0], ra, B, H, W, st));
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][0], ra, rc_, B, H, W, st));
+    }
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][1], rc_, ra, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][2], ra, rc_, B, H, W, st));
     LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][3], rc_, ra, B, H, W, st));
@@ -597,7 +581,7 @@ struct DeferState {
     bool pred1_unwritten = false;
     hipEvent_t stage1_stop = nullptr;        // lws_forward's second fork: complete once stage 1's Conv3D stack is (conv3d_stack's last_stop)
     int stage1_stop_after = 0;               // ... or once its k-th middle layer is (option "fork2_after")
-    bool stage1_stop_set = false;
+    bool stage1_stop_ext = false;            // bound to that kernel's completion signal (not under hipGraph capture)
     bool def[3] = {false, false, false};
     const float *low[3] = {nullptr, nullptr, nullptr};
     int lh[3] = {0, 0, 0}, lw[3] = {0, 0, 0};
@@ -615,13 +599,11 @@ static int refine_rest(lws_ctx *h, float *pred3, int B, int H, int W, const WsLa
     const int CH = (ds != nullptr && ds->def[2]) ? B : refine_chunk(h, B, H, W);      // (deferred maps: batches <= 2, one chunk)
     // Option "ref_pipe": chunks alternate between the caller's stream and the side stream (idle by now), each starting once the
     // previous chunk has finished its disparity branch, so that one chunk's memory-bound blocks run beside the other's MFMA-bound
-    // 64 -> 32 convolution; odd chunks use the second half of the (batch-sized) scratch maps.  Measured r03: 8 x 368x1232 (eight
-    // chunks of one pair) 810 -> 833 pairs/s; 8 x 256x512 (two chunks of four) 2,958 -> 2,930: two chunks only add their
+    // 64 -> 32 convolution; odd chunks use the second half of the (batch-sized) scratch maps.  Two chunks only add their
     // collisions, hence the automatic setting wants at least four.
     // refinement2[4] + refinement2[5] + pred3 in one launch (k_ref_dws_last): option "fuse_ref_last"; automatic = batch 1 only
-    // (measured round 5, pairs/s fused vs two launches: 2,061-2,076 vs 2,047-2,071 at batch 1, 2,569 vs 2,581 at batch 2, 2,988 vs
-    // 3,013 at batch 8, 837 vs 840 at 8 x 368x1232 -- the fused launch takes as long as the two it replaces, 19.3 vs 10.9 + 8.6 us,
-    // so all it buys is one dispatch gap: profiles/r05/experiments/ab_fuse_ref_last.txt)
+    // (the fused launch takes as long as the two it replaces, so all it buys is one dispatch gap).
+    // Numbers for both: profiles/NOTES.md, "refinement launch plan".
     const bool fuse_last = h->opt.fuse_ref_last >= 0 ? h->opt.fuse_ref_last != 0 : B <= 1;
     const int nchunks = (B + CH - 1) / CH;
     const int want = h->opt.ref_pipe >= 0 ? h->opt.ref_pipe : (nchunks >= 4 ? 1 : 0);
@@ -655,14 +637,14 @@ static int refine_rest_chunk(lws_ctx *h, float *pred3, int B, int H, int W, cons
     float *ra = h->ws + L.r_a + (size_t)b0 * H * W * 32, *rb = h->ws + L.r_b + (size_t)scratch_b0 * H * W * 32,
           *rc_ = h->ws + L.r_c + (size_t)scratch_b0 * H * W * 32;
     int rc;
-    if (h->opt.fuse_first && ref_first_dws_can_fuse(n.r1[1][0], 1)) {
+    if ((h->opt.fuse_first & 1) && ref_first_dws_can_fuse(n.r1[1][0], 1)) {
         // refinement1_disp: the 1 -> 32 convolution is recomputed inside the first block's staging (one launch less)
         if (ds != nullptr && ds->def[2]) {
             // pred3 = upsample(low[2]) + pred2 was not materialised: this kernel evaluates it and writes it out
-            LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[1][0], pred2, n.r1_first[1], rc_, B, H, W, st, ds->low[2],
-                                                        ds->lh[2], ds->lw[2], pred3));
+            LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[1][0], pred2, 1, n.r1_first[1], rc_, B, H, W, st, ds->low[2],
+                                                        ds->lh[2], ds->lw[2], pred3, ioff_of(h)));
         } else {
-            LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[1][0], pred3, n.r1_first[1], rc_, B, H, W, st));
+            LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[1][0], pred3, 1, n.r1_first[1], rc_, B, H, W, st));
         }
     } else {
         LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(pred3, 1, n.r1_first[1], rb, B, H, W, st));
@@ -690,7 +672,7 @@ static int refine_rest_chunk(lws_ctx *h, float *pred3, int B, int H, int W, cons
 
 static bool refine_can_defer(const lws_ctx *h)
 {
-    return h->opt.fuse_first && h->have_2d && ref_first_dws_can_fuse(h->net2d.r1[1][0], 1);
+    return (h->opt.fuse_first & 1) && h->have_2d && ref_first_dws_can_fuse(h->net2d.r1[1][0], 1);
 }
 
 static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *const featsR[3], int B, int H, int W,
@@ -720,16 +702,15 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         if (!ds->pred1_unwritten) return LWS_OK;
         ds->pred1_unwritten = false;
         ProfScope p(h, LWS_KC_UPSAMPLE, st);
-        return launch_upsample_add(ds->low[0], nullptr, pred_out[0], B, ds->lh[0], ds->lw[0], H, W, st);       // :145-148
+        return launch_upsample_add(ds->low[0], nullptr, pred_out[0], B, ds->lh[0], ds->lw[0], H, W, st, ioff_of(h));   // :145-148
     };
     for (int s = 0; s < 3; ++s) {
         int D, hh, ww;
         stage_dims(h, s, H, W, D, hh, ww);
         float *low = h->ws + L.low[s];
         if (s > 0 && feat_ready != nullptr && feat_ready[s] != nullptr) LWS_HIP(hipStreamWaitEvent(st, feat_ready[s], 0));
-        const bool fuse_shift = h->opt.fuse_shift != 0;   // default on (measured r01: +0.3 % at batch 1, +0.7 % at batch 8)
         bool first_done = false;
-        if (s == 0 && fuse_shift && shift_first_can_fuse(h->stage[0], feat_c[0])) {
+        if (s == 0 && shift_first_can_fuse(h->stage[0], feat_c[0])) {
             // stage-1 volume and the first Conv3D layer in one launch (the raw volume is still written: skip input)
             ProfScope p(h, LWS_KC_CONV3D_FIRST, st);
             rc = launch_shift_first(h->stage[0], featsL[0], featsR[0], raw, act_a, B, feat_c[0], D, hh, ww, st,
@@ -748,13 +729,13 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
                                        hh, ww, H, W, h->cfg.maxdisplist[s], st, h->cfg.feature_fp16 != 0, ds->low[s - 1],
                                        ds->lh[s - 1], ds->lw[s - 1], s == 2 ? pred_out[s - 1] : nullptr, h->opt.warp_form,
                                        two ? ds->low[0] : nullptr, two ? ds->lh[0] : 0, two ? ds->lw[0] : 0,
-                                       two ? pred_out[0] : nullptr);
+                                       two ? pred_out[0] : nullptr, ioff_of(h));
             if (two) ds->pred1_unwritten = false;
         } else {
             ProfScope p(h, LWS_KC_VOLUME_WARP, st);
             rc = launch_volume_l1_warp(featsL[s], featsR[s], pred_out[s - 1], raw, nullptr, B, feat_c[s], hh, ww, H, W,
                                        h->cfg.maxdisplist[s], st, h->cfg.feature_fp16 != 0, nullptr, 0, 0, nullptr,
-                                       h->opt.warp_form);                                                     // :119-127
+                                       h->opt.warp_form, nullptr, 0, 0, nullptr, ioff_of(h));                 // :119-127
         }
         if (rc) return rc;
         const float start = s == 0 ? 0.0f : (float)(-h->cfg.maxdisplist[s] + 1);
@@ -763,9 +744,9 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         // k_softargmin_upsample launch does soft-argmin AND upsample in one kernel
         const bool defer_first = s == 0 && defer_up && h->opt.fuse_last1 != 0 && ds->allow_first && B <= 2 && H % 2 == 0 && W % 2 == 0;
         rc = conv3d_stack(h, s, raw, cost, act_a, act_b, B, D, hh, ww, st, (s > 0 || defer_first) ? low : nullptr, start, &fused,
-                          first_done, s == 0 ? ds->stage1_stop : nullptr, s == 0 ? ds->stage1_stop_after : 0);   // :136-138
+                          first_done, s == 0 ? ds->stage1_stop : nullptr, s == 0 ? ds->stage1_stop_after : 0,
+                          s == 0 && ds->stage1_stop_ext);                                                        // :136-138
         if (rc) return rc;
-        if (s == 0 && ds->stage1_stop != nullptr) ds->stage1_stop_set = true;
         if (s == 0 && after_stage1_stack) {
             rc = after_stage1_stack();
             if (rc) return rc;
@@ -789,7 +770,7 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
             if (H % hh == 0 && W % ww == 0) {
                 ProfScope p(h, LWS_KC_SOFTARGMIN, st);
                 rc = launch_softargmin_upsample(cost, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], nullptr, B, D, hh, ww,
-                                                H, W, start, st);
+                                                H, W, start, st, ioff_of(h));
             } else {
                 // H or W = 8k-1: the resize ratio is not an integer, which the fused kernel's tile -> block map needs
                 {
@@ -798,14 +779,14 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
                 }
                 if (rc) return rc;
                 ProfScope p(h, LWS_KC_UPSAMPLE, st);
-                rc = launch_upsample_add(low, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], B, hh, ww, H, W, st);
+                rc = launch_upsample_add(low, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], B, hh, ww, H, W, st, ioff_of(h));
             }
             if (rc) return rc;
             continue;
         }
-        // stage 2's map is consumed by stage 3's warp at exactly half resolution; stage 3's by the refinement
-        // (measured r01: two launches fewer are worth +0.5 % at batch 1; at batch 8 the heavier consumers cost 1.2 %, so
-        // large batches keep the separate k_upsample_add launches)
+        // stage 2's map is consumed by stage 3's warp at exactly half resolution; stage 3's by the refinement (two launches
+        // fewer on a batch-1 chain; from batch 4 up the heavier consumers cost more than the launches, so large batches keep
+        // the separate k_upsample_add launches)
         // (only at exact 2x geometry: with odd H or W the four taps of a stage-3 pixel are not the 2x2 block it owns)
         if (defer_this) {
             ds->def[s] = true;
@@ -816,7 +797,7 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
         }
         {
             ProfScope p(h, LWS_KC_UPSAMPLE, st);
-            rc = launch_upsample_add(low, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], B, hh, ww, H, W, st);   // :145-156
+            rc = launch_upsample_add(low, s == 0 ? nullptr : pred_out[s - 1], pred_out[s], B, hh, ww, H, W, st, ioff_of(h));   // :145-156
         }
         if (rc) return rc;
     }
@@ -849,16 +830,9 @@ static int check_device(const lws_ctx *h, const char *what)
         if (rc_dev_) return rc_dev_;           \
     } while (0)
 
-// side streams and cross-stream events of lws_forward: created by lws_reserve (which promises that later calls allocate
-// nothing) or, for callers that never reserve, on the first forward
-// (Round 5, built, measured, removed: a CU-masked side stream, hipExtStreamCreateWithCUMask -- VERDICT r4 item 2b.  Whole-XCD
-// masks do not exist on this part: bit i of the mask is CU slot i / 8 of XCD i % 8, the dispatcher hands workgroups to all 8
-// XCDs whatever the mask says, and a mask that leaves an XCD empty ran as if unmasked or hung (tools/micro/cumask.hip).  A
-// per-XCD CU budget (the low 8 k bits) works as a mask but not as a plan: with ANY masked stream in the process every kernel
-// of the forward slowed down, also those on the unmasked stream -- 8 x 256x512: 2,989 pairs/s unmasked, 1,407 / 1,881 / 2,094 /
-// 2,226 / 2,363 with 4 / 8 / 12 / 16 / 24 CUs per XCD; batch 1: 2,060 -> 922-993; 8 x 368x1232: 831 -> 421-708 -- and a plain
-// copy kernel on a 64-CU mask hung until its timeout.  profiles/r05/experiments/sweep_side_cus_per_xcd_budget.txt,
-// sweep_side_xcds_whole_xcd_masks.txt, profiles/r05/micro_cumask.txt.)
+// side stream and cross-stream events of lws_forward: created by lws_reserve (which promises that later calls allocate
+// nothing) or, for callers that never reserve, on the first forward.  (A CU-masked side stream was built, measured and removed
+// in round 5: profiles/NOTES.md, "CU masks".)
 static int ensure_streams(lws_ctx *h)
 {
     if (h->side) return LWS_OK;
@@ -867,8 +841,6 @@ static int ensure_streams(lws_ctx *h)
     LWS_HIP(hipEventCreateWithFlags(&h->ev_fork, ef));
     LWS_HIP(hipEventCreateWithFlags(&h->ev_join, ef));
     for (int i = 0; i < 3; ++i) LWS_HIP(hipEventCreateWithFlags(&h->ev_feat[i], ef));
-    LWS_HIP(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
-    LWS_HIP(hipEventCreateWithFlags(&h->ev_right, ef));
     LWS_HIP(hipEventCreateWithFlags(&h->ev_fork2, ef));
     return LWS_OK;
 }
@@ -901,6 +873,8 @@ int lws_create(const lws_config *cfg, lws_handle *out)
                       "stage %d: channels_3d*growth_rate = %d is not supported by the gfx950 kernels (8, 16, 32)", i, c3);
     }
     LWS_CHECK_ARG(cfg->feature_fp16 == 0 || cfg->feature_fp16 == 1, "feature_fp16 must be 0 or 1 (got %d)", cfg->feature_fp16);
+    LWS_CHECK_ARG(cfg->interp_align_mode == 0 || cfg->interp_align_mode == 1, "interp_align_mode must be 0 or 1 (got %d)",
+                  cfg->interp_align_mode);
     lws_ctx *h = new (std::nothrow) lws_ctx();
     if (!h) {
         set_error("out of host memory");
@@ -919,40 +893,27 @@ int lws_create(const lws_config *cfg, lws_handle *out)
 static void apply_options(lws_ctx *h)
 {
     for (int i = 0; i < 3; ++i) {
-        h->stage[i].mid8_form = h->opt.mid8_form;
-        h->stage[i].dfast = h->opt.conv3d_order;
-        h->stage[i].mid16_form = h->opt.mid16_form;
-        h->stage[i].mid8_balance = h->opt.mid8_balance;
-        // (experiment knob: values >= 8 address the stages separately -- stage 2 takes v % 8, stage 3 v / 8)
-        h->stage[i].mid8_tile = h->opt.mid8_tile < 8 ? h->opt.mid8_tile : (i == 2 ? h->opt.mid8_tile / 8 : h->opt.mid8_tile % 8);
+        h->stage[i].mid16_split = (h->opt.split_bf16 & 1) != 0;
+        h->stage[i].mid8_split = (h->opt.split_bf16 & 2) != 0;
+        h->stage[i].mid8_balance = h->mid8_balance;
         h->stage[i].cu_count = h->cu_count;
     }
-    h->net2d.r2_first.form = h->opt.conv64_form;
+    h->net2d.r2_first.form = (h->opt.split_bf16 & 4) ? 1 : 0;
 }
 
 static int *option_slot(lws_ctx *h, const char *name)
 {
-    struct { const char *name; int *slot; } tab[] = {{"left_at", &h->opt.left_at},
-                                                     {"split_heads", &h->opt.split_heads},
-                                                     {"fuse_shift", &h->opt.fuse_shift},
-                                                     {"fuse_first", &h->opt.fuse_first},
+    struct { const char *name; int *slot; } tab[] = {{"fuse_first", &h->opt.fuse_first},
                                                      {"defer_upsample", &h->opt.defer_upsample},
                                                      {"side_streams", &h->opt.side_streams},
-                                                     {"conv3d_order", &h->opt.conv3d_order},
-                                                     {"mid16_form", &h->opt.mid16_form},
-                                                     {"conv64_form", &h->opt.conv64_form},
+                                                     {"split_bf16", &h->opt.split_bf16},
                                                      {"ref_chunk_mb", &h->opt.ref_chunk_mb},
                                                      {"ref_pipe", &h->opt.ref_pipe},
                                                      {"warp_form", &h->opt.warp_form},
-                                                     {"mid8_balance", &h->opt.mid8_balance},
                                                      {"fuse_last1", &h->opt.fuse_last1},
-                                                     {"mid8_tile", &h->opt.mid8_tile},
-                                                     {"fork_ext", &h->opt.fork_ext},
                                                      {"fork2_after", &h->opt.fork2_after},
-                                                     {"tail_at", &h->opt.tail_at},
                                                      {"fuse_ref_last", &h->opt.fuse_ref_last},
-                                                     {"device", &h->device},
-                                                     {"mid8_form", &h->opt.mid8_form}};
+                                                     {"device", &h->device}};
     for (auto &e : tab)
         if (strcmp(e.name, name) == 0) return e.slot;
     return nullptr;
@@ -961,21 +922,15 @@ static int *option_slot(lws_ctx *h, const char *name)
 int lws_set_option(lws_handle h, const char *name, int value)
 {
     LWS_CHECK_ARG(h && name, "lws_set_option: null argument");
-    if (strcmp(name, "split_bf16") == 0) {
-        // the opt-in numerics mode as one switch: every MFMA convolution that has a split-bf16 form (NOT bit-exact)
-        LWS_CHECK_ARG(value == 0 || value == 1, "lws_set_option: split_bf16 must be 0 or 1 (got %d)", value);
-        h->opt.mid16_form = value;
-        h->opt.conv64_form = value;
-        h->opt.mid8_form = value ? 2 : 1;
-        apply_options(h);
-        return LWS_OK;
-    }
     int *slot = option_slot(h, name);
     LWS_CHECK_ARG(slot != nullptr, "lws_set_option: unknown option '%s'", name);
-    if (strcmp(name, "left_at") == 0)
-        LWS_CHECK_ARG(value == -1 || value == 0 || value == 2, "lws_set_option: left_at must be -1 (auto), 0 or 2 (got %d)", value);
-    else if (strcmp(name, "split_heads") == 0 || strcmp(name, "ref_pipe") == 0 || strcmp(name, "fuse_ref_last") == 0 || strcmp(name, "tail_at") == 0)
-        LWS_CHECK_ARG(value >= -1 && value <= (strcmp(name, "tail_at") == 0 ? 2 : 1), "lws_set_option: %s is out of range (got %d)", name, value);
+    if (strcmp(name, "split_bf16") == 0)
+        // the opt-in numerics mode: a bit per MFMA convolution that has a split-bf16 form (NOT bit-exact); 7 = all of them
+        LWS_CHECK_ARG(value >= 0 && value <= 7, "lws_set_option: split_bf16 is a bit mask in 0..7 (got %d)", value);
+    else if (strcmp(name, "fuse_first") == 0)
+        LWS_CHECK_ARG(value >= 0 && value <= 3, "lws_set_option: fuse_first is a bit mask in 0..3 (got %d)", value);
+    else if (strcmp(name, "ref_pipe") == 0 || strcmp(name, "fuse_ref_last") == 0)
+        LWS_CHECK_ARG(value >= -1 && value <= 1, "lws_set_option: %s is out of range (got %d)", name, value);
     else if (strcmp(name, "ref_chunk_mb") == 0)
         LWS_CHECK_ARG(value >= 0 && value <= 4096, "lws_set_option: ref_chunk_mb must be in 0..4096 (got %d)", value);
     else if (strcmp(name, "device") == 0) {
@@ -984,12 +939,8 @@ int lws_set_option(lws_handle h, const char *name, int value)
                       "lws_set_option: the device of a handle can only be changed before lws_finalize / lws_reserve "
                       "have allocated on device %d", h->device);
     }
-    else if (strcmp(name, "mid8_form") == 0)
-        LWS_CHECK_ARG(value >= 0 && value <= 2, "lws_set_option: mid8_form must be 0, 1 or 2 (got %d)", value);
     else if (strcmp(name, "fork2_after") == 0)
         LWS_CHECK_ARG(value >= -1 && value <= 16, "lws_set_option: fork2_after must be in -1..16 (got %d)", value);
-    else if (strcmp(name, "mid8_tile") == 0)
-        LWS_CHECK_ARG(value >= 0 && value <= 39 && value % 8 <= 4, "lws_set_option: mid8_tile must be t or t2 + 8 * t3 with t in 0..4 (got %d)", value);
     else
         LWS_CHECK_ARG(value == 0 || value == 1, "lws_set_option: %s must be 0 or 1 (got %d)", name, value);
     *slot = value;
@@ -1000,10 +951,6 @@ int lws_set_option(lws_handle h, const char *name, int value)
 int lws_get_option(lws_handle h, const char *name, int *value)
 {
     LWS_CHECK_ARG(h && name && value, "lws_get_option: null argument");
-    if (strcmp(name, "split_bf16") == 0) {
-        *value = (h->opt.mid16_form == 1 && h->opt.conv64_form == 1 && h->opt.mid8_form == 2) ? 1 : 0;
-        return LWS_OK;
-    }
     int *slot = option_slot(h, name);
     LWS_CHECK_ARG(slot != nullptr, "lws_get_option: unknown option '%s'", name);
     *value = *slot;
@@ -1066,6 +1013,51 @@ int lws_profile_read_class(lws_handle h, int kernel_class, float *ms_out, int ca
     return LWS_OK;
 }
 
+int lws_clock_probe(lws_handle h, int B, int H, int W, void *stream, double *ghz)
+{
+    LWS_CHECK_ARG(h && ghz, "lws_clock_probe: null argument");
+    int rc = check_size(h, B, H, W);
+    if (rc) return rc;
+    LWS_CHECK_DEVICE(h, "lws_clock_probe");
+    if (!h->finalized || h->stage[0].c3 == 8) {
+        set_error("lws_clock_probe: needs a finalized model whose stage-1 stack runs k_conv3d_mid16 (C3 = 16 or 32)");
+        return LWS_ERR_STATE;
+    }
+    const WsLayout L = ws_layout(h, B, H, W);
+    rc = ensure_ws(h, L.total);
+    if (rc) return rc;
+    constexpr int kWg = 64, kRuns = 8;
+    if (!h->clk_buf) LWS_HIP(hipMalloc(&h->clk_buf, kWg * 4 * sizeof(unsigned long long)));
+    hipStream_t st = (hipStream_t)stream;
+    LWS_HIP(hipMemsetAsync(h->clk_buf, 0, kWg * 4 * sizeof(unsigned long long), st));
+    int D, hh, ww;
+    stage_dims(h, 0, H, W, D, hh, ww);
+    (void)stop_event_take();
+    // the stage-1 middle layer on whatever the workspace holds (the activations of the last forward, or anything finite
+    // enough: the timing does not depend on the values), back to back; the last launch carries the stamps
+    for (int i = 0; i < kRuns && rc == LWS_OK; ++i) {
+        h->stage[0].clk = i == kRuns - 1 ? h->clk_buf : nullptr;
+        rc = launch_conv3d_mid(h->stage[0], 1, h->ws + L.act_a, h->ws + L.act_b, B, D, hh, ww, st);
+    }
+    h->stage[0].clk = nullptr;
+    if (rc) return rc;
+    unsigned long long host[kWg * 4];
+    LWS_HIP(hipMemcpyAsync(host, h->clk_buf, sizeof(host), hipMemcpyDeviceToHost, st));
+    LWS_HIP(hipStreamSynchronize(st));
+    std::vector<double> v;
+    for (int i = 0; i < kWg; ++i) {
+        const unsigned long long c0 = host[4 * i], r0 = host[4 * i + 1], c1 = host[4 * i + 2], r1 = host[4 * i + 3];
+        if (r1 > r0 && c1 > c0) v.push_back((double)(c1 - c0) / (double)(r1 - r0) * 0.1);      // shader cycles per 10 ns tick -> GHz
+    }
+    if (v.empty()) {
+        set_error("lws_clock_probe: no workgroup left a usable stamp");
+        return LWS_ERR_STATE;
+    }
+    std::sort(v.begin(), v.end());
+    *ghz = v[v.size() / 2];
+    return LWS_OK;
+}
+
 const char *lws_kernel_class_name(int kc)
 {
     static const char *names[LWS_KC_COUNT] = {"volume_l1_shift", "volume_l1_warp", "conv3d_first", "conv3d_mid16",
@@ -1086,11 +1078,9 @@ int lws_destroy(lws_handle h)
         (void)hipEventDestroy(h->ev_fork);
         (void)hipEventDestroy(h->ev_join);
         for (int i = 0; i < 3; ++i) (void)hipEventDestroy(h->ev_feat[i]);
-        (void)hipStreamSynchronize(h->side2);
-        (void)hipStreamDestroy(h->side2);
-        (void)hipEventDestroy(h->ev_right);
         if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
     }
+    if (h->clk_buf) (void)hipFree(h->clk_buf);
     if (h->params && h->owns_params) (void)hipFree(h->params);
     if (h->ws) (void)hipFree(h->ws);
     delete h;
@@ -1265,6 +1255,7 @@ int lws_conv3d_stack(lws_handle h, int stage, const float *cost_in, float *cost_
     const size_t act = ((size_t)B * D * hh * ww * h->stage[stage].c3 + 63) & ~(size_t)63;
     int rc = ensure_ws(h, 2 * act);
     if (rc) return rc;
+    (void)stop_event_take();
     return conv3d_stack(h, stage, cost_in, cost_out, h->ws, h->ws + act, B, D, hh, ww, (hipStream_t)stream);
 }
 
@@ -1299,6 +1290,7 @@ int lws_disparity_stages(lws_handle h, const float *const featsL[3], const float
     const WsLayout L = ws_layout(h, B, H, W);
     rc = ensure_ws(h, L.total);
     if (rc) return rc;
+    (void)stop_event_take();
     return stages_impl(h, featsL, featsR, B, H, W, pred_out, L, (hipStream_t)stream);
 }
 
@@ -1317,6 +1309,7 @@ int lws_feature_extraction(lws_handle h, const float *img, int N, int H, int W, 
     const WsLayout L = ws_layout(h, (N + 1) / 2, H, W);
     int rc = ensure_ws(h, L.total_all);
     if (rc) return rc;
+    (void)stop_event_take();
     return feature_extraction(h, img, nullptr, N, 0, H, W, L, f8, f4, f2, (hipStream_t)stream);
 }
 
@@ -1353,122 +1346,73 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
     rc = ensure_ws(h, L.total_all);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    (void)stop_event_take();   // (an error return of an earlier call on this thread may have left a stop event armed)
+    (void)stop_event_take();
+    // Under hipGraph capture (tools/graph_pipeline.py; lws_reserve first, so that nothing allocates) the forks must be capture-
+    // time records -- hipEventRecord on the capturing stream, which is what pulls the side stream into the graph; an event bound
+    // to a kernel's completion signal is not one -- and nothing is profiled (timing events cannot be read back from a graph).
+    bool capturing = false;
+    if (st != nullptr) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        LWS_HIP(hipStreamIsCapturing(st, &cs));
+        capturing = cs != hipStreamCaptureStatusNone;
+    }
     // profiler sampling (lws_profile_sample): only every n-th forward call records events
     struct MaskGuard {
         lws_ctx *h;
         ~MaskGuard() { h->prof_mask = h->prof_mask_cfg; }
     } mask_guard{h};
-    h->prof_mask = (h->prof_every <= 1 || h->prof_calls++ % (unsigned)h->prof_every == 0) ? h->prof_mask_cfg : 0u;
-    // Two independent branches run on handle-owned side streams (speed only): refinement1_left, which depends on the
-    // left image only, and the tail of the feature extractor.  Option "side_streams" = 0 keeps everything on the caller's
-    // stream: no forks, joins or event bubbles -- the plan lws_pool uses, where the kernels of OTHER forwards fill the CUs
-    // and three streams map onto three hardware queues instead of nine onto four.
+    h->prof_mask = (!capturing && (h->prof_every <= 1 || h->prof_calls++ % (unsigned)h->prof_every == 0)) ? h->prof_mask_cfg : 0u;
+    // Two independent branches run on the handle-owned side stream (speed only): the tail of the feature extractor and
+    // refinement1_left, which depends on the left image only.  Option "side_streams" = 0 keeps everything on the caller's
+    // stream: no forks, joins or event bubbles -- the plan lws_pool uses, where the kernels of OTHER forwards fill the CUs.
+    // The plan (what was measured against what: profiles/NOTES.md, "launch plan of lws_forward"):
+    //   caller's stream: feature head -> stage 1 -> stage 2 -> stage 3 -> refinement1_disp, refinement2
+    //   fork 1, behind the feature head:                    conv5 (-> the 1/4 map of stage 2)
+    //   fork 2, behind stage 1's last middle Conv3D layer:  conv6 + classif1 (-> the 1/2 map of stage 3), refinement1_left
+    //   joins: the 1/4 map before stage 2, the 1/2 map before stage 3, refinement1_left before the refinement.
+    // refinement1_left is HBM-bound work beside stages 2 and 3, whose MFMA kernels keep their weights in registers and do not
+    // mind; beside stage 1 it would slow k_conv3d_mid16, which streams its weights from L2.
     const bool multi = h->opt.side_streams != 0;
     if (multi) {
         rc = ensure_streams(h);
         if (rc) return rc;
     }
     hipStream_t side = multi ? h->side : st;
-    // refinement1_left (5 kernels, 58 us of HBM-bound work at batch 1) depends on the left image only.  It runs on the side
-    // stream beside stages 2 and 3, whose MFMA kernels keep their weights in registers and do not mind; beside the feature
-    // head it spilled into stage 1, where k_conv3d_mid16's weight stream from L2 does mind (measured r01: 1,953 vs 1,934
-    // pairs/s at batch 1; r03, with the refinement in cache-sized chunks: 2,784 vs 2,669 at batch 4, 2,879 vs 2,810 at
-    // batch 8, 800 vs 790 at 8 x 368x1232 -- k_conv3d_mid16 then runs at 0.79-0.80 of the fp32-MFMA peak in situ instead of
-    // 0.66).  lws_set_option("left_at", 0) starts it with the forward instead.
-    const int left_at = h->opt.left_at >= 0 ? h->opt.left_at : 2;
-    // ev_fork orders both side streams behind everything already queued on st (the previous forward's readers of the
-    // buffers they overwrite, the producers of left/right): recorded whenever either consumer of it runs -- the early
-    // refinement1_left below or the right-image feature head on side2 (feature_extraction, batches >= 4)
-    if (multi && (left_at == 0 || split_heads(h, B))) LWS_HIP(hipEventRecord(h->ev_fork, st));
-    if (left_at == 0) {
-        if (multi) LWS_HIP(hipStreamWaitEvent(side, h->ev_fork, 0));
-        rc = refine_left(h, left, B, H, W, L, side);                                        // models.py:158
-        if (rc) return rc;
-        if (multi) LWS_HIP(hipEventRecord(h->ev_join, side));
-    }
+    const bool ext = multi && !capturing;       // forks ride on their producer kernel's completion signal (StopArm)
     float *f8 = h->ws + L.fe_f8, *f4 = h->ws + L.fe_f4, *f2 = h->ws + L.fe_f2;
-    // Cross-stream hand-offs cost the stream that carries the chain (tools/micro/event_cost.hip, round 5): a fork by
-    // hipEventRecord 2.6 us, by an event bound to the producer kernel's completion signal 1.3 us (option "fork_ext"); a join --
-    // hipStreamWaitEvent on an event that is not complete when the HOST calls it, which is always the case here because the host
-    // runs a forward ahead of the device -- 5 us, even when the event is long complete by the time the command processor gets
-    // there.  The chain has two forks (after the feature head; after stage 1's Conv3D stack) and three joins (f4 before stage
-    // 2, f2 before stage 3, refinement1_left before the refinement).  Option "tail_at" = 0 starts the whole feature tail at the
-    // first fork: f4 and f2 then share ONE join (before stage 2), at the price of three more short kernels beside stage 1.
-    const bool fork_ext = multi && h->opt.fork_ext != 0 && !split_heads(h, B);
-    // Measured round 5 (profiles/r05/experiments/ab_fork_tail.txt, pairs/s): "tail_at" 0 vs 1 at batch 1: 1,994-2,008 vs
-    // 2,107-2,119 -- the three extra kernels beside stage 1 cost k_conv3d_mid16 1.5-2.7 us per launch (24.4 -> 25.9-27.2 us),
-    // far more than the join they save; 2,534 vs 2,579 at batch 2, 2,888 vs 2,924 at batch 4, 3,053 vs 3,021 at batch 8 (one
-    // sample).  "fork_ext" 1 vs 0 at batch 1: 2,107-2,119 vs 2,093-2,108 (+0.5 %).  "tail_at" 2 (conv5 too at the second fork, no
-    // first fork; with the second fork behind the last MIDDLE layer conv5 runs beside stage 1's last layer): k_conv3d_mid16 24.1-24.4
-    // instead of 24.3-24.6 us, but stage 2 then waits for its 1/4 map: 2,046-2,082 vs 2,112-2,132 at batch 1; 2,645 vs 2,589 at
-    // batch 2, 2,941 vs 2,952 at batch 4, 3,045 vs 3,040 at batch 8, 843 vs 844 at 8 x 368x1232 (one sample each).
-    // Automatic: conv5 at the first fork, the rest at the second.
-    const int tail_at = h->opt.tail_at >= 0 ? h->opt.tail_at : 1;
-    // ("tail_at" = 2: conv5 too waits for the second fork -- no first fork at all)
-    rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st, side, h->ev_feat,
-                            (fork_ext && tail_at != 2) ? h->ev_feat[0] : nullptr);                       // models.py:110-111
+    rc = feature_extraction(h, left, right, B, B, H, W, L, f8, f4, f2, st, /*head_only=*/true,
+                            multi ? h->ev_feat[0] : nullptr, ext);                                    // models.py:110-111
     if (rc) return rc;
     const size_t n2 = (size_t)B * 8 * half_up(H) * half_up(W), n4 = n2 / 2, n8 = n2 / 8;   // 8 / 16 / 16 channels
     const float *fl[3] = {f8, f4, f2};
     const float *fr[3] = {f8 + n8, f4 + n4, f2 + n2};
-    // The rest of the feature extractor (f4 for stage 2, f2 for stage 3) runs on the side stream.  conv5 -> f4 is one short
-    // kernel and goes there at once, so stage 2 never waits for it; conv6 + classif1 -> f2 follow it ("tail_at" = 0) or start
-    // after stage 1's Conv3D stack ("tail_at" = 1: beside stage 1's regression and stage 2 instead of beside the MFMA-bound
-    // stage-1 kernels).
-    if (tail_at != 2) {
-        if (multi) {
-            if (!fork_ext) LWS_HIP(hipEventRecord(h->ev_feat[0], st));
-            LWS_HIP(hipStreamWaitEvent(side, h->ev_feat[0], 0));
-        }
-        rc = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, tail_at == 0 ? 3 : 1);
-        if (rc) return rc;
-    }
+    if (multi) LWS_HIP(hipStreamWaitEvent(side, h->ev_feat[0], 0));
+    rc = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, 1);          // conv5 -> f4
+    if (rc) return rc;
     DeferState ds;
     ds.allow_last = refine_can_defer(h);
     ds.allow_first = true;
-    // Where the second fork sits (option "fork2_after": k = behind stage 1's k-th middle layer, 0 = behind its last layer, -1 =
-    // automatic).  Measured round 5 (profiles/r05/experiments/ab_fork2_after.txt, pairs/s, behind the last layer | the 4th | the
-    // 3rd middle layer): batch 1 2,109-2,111 | 2,118-2,126 | 2,076-2,082; batch 2 2,588-2,590 | 2,579-2,597 | 2,597-2,606; batch 4
-    // 2,882-2,938 | 2,958-2,964 | 2,958-2,964; batch 8 3,049-3,055 | 3,051-3,062 | 3,066-3,072; 8 x 368x1232 847-848 | 847-852 |
-    // 854-855.  Behind the last middle layer every k_conv3d_mid16 launch still runs undisturbed (the side branch starts beside the
-    // stack's last layer); behind the third, the fourth launch has company: at batch 1 that costs more than the earlier start
-    // gives, from batch 2 up it gives another 0.3-0.6 % of the step while the dominant kernel's in-situ rate drops from 0.78-0.80
-    // to 0.76 of the fp32-MFMA peak (175 -> 182 us per launch at batch 8).  Automatic: behind the last middle layer at every
-    // batch -- the simple rule, and the one that leaves the dominant kernel alone; "fork2_after" = 3 is there for whoever wants
-    // the last half per cent of a large batch.  The event rides on that kernel's completion signal ("fork_ext") or is recorded
-    // behind it: conv3d_stack handles both.
+    // where the second fork sits: option "fork2_after" (k = behind stage 1's k-th middle layer, 0 = behind its last layer,
+    // -1 = automatic: the last middle layer, which leaves every k_conv3d_mid16 launch undisturbed)
     const int L3 = h->cfg.layers_3d;
     int fork2 = h->opt.fork2_after;
     if (fork2 < 0) fork2 = L3;
     if (fork2 > L3) fork2 = 0;
-    if (multi && (fork_ext || fork2 != 0)) {
+    if (multi) {
         ds.stage1_stop = h->ev_fork2;
         ds.stage1_stop_after = fork2;
+        ds.stage1_stop_ext = ext;
     }
     auto launch_tail = [&]() -> int {
-        if (tail_at == 0 && left_at != 2) return LWS_OK;          // nothing is started here
-        if (multi) {
-            hipEvent_t fe = h->ev_feat[0];
-            if (ds.stage1_stop_set)
-                fe = ds.stage1_stop;                              // already bound to (or recorded behind) stage 1's last kernel
-            else
-                LWS_HIP(hipEventRecord(fe, st));
-            LWS_HIP(hipStreamWaitEvent(side, fe, 0));
-        }
-        if (tail_at != 0) {
-            int r2 = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, tail_at == 2 ? 3 : 2);
-            if (r2) return r2;
-        }
-        if (left_at == 2) {
-            int r2 = refine_left(h, left, B, H, W, L, side);
-            if (r2) return r2;
-            if (multi) LWS_HIP(hipEventRecord(h->ev_join, side));
-        }
+        if (multi) LWS_HIP(hipStreamWaitEvent(side, h->ev_fork2, 0));     // (bound or recorded by conv3d_stack)
+        int r2 = feature_tail(h, 2 * B, H, W, L, f8, f4, f2, side, multi ? h->ev_feat : nullptr, 2);   // conv6, classif1 -> f2
+        if (r2) return r2;
+        r2 = refine_left(h, left, B, H, W, L, side);                                                    // models.py:158
+        if (r2) return r2;
+        if (multi) LWS_HIP(hipEventRecord(h->ev_join, side));
         return LWS_OK;
     };
-    // joins: f4 before stage 2 and f2 before stage 3 -- or, with the whole tail issued together, both before stage 2
-    hipEvent_t ready[3] = {nullptr, tail_at == 0 ? h->ev_feat[2] : h->ev_feat[1], tail_at == 0 ? nullptr : h->ev_feat[2]};
+    hipEvent_t ready[3] = {nullptr, h->ev_feat[1], h->ev_feat[2]};        // joins: f4 before stage 2, f2 before stage 3
     rc = stages_impl(h, fl, fr, B, H, W, pred_out, L, st, multi ? ready : nullptr, launch_tail, &ds);   // :115-156
     if (rc) return rc;
     if (multi) LWS_HIP(hipStreamWaitEvent(st, h->ev_join, 0));

@@ -35,13 +35,15 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 
 #define LWS_LAUNCH_CHECK() LWS_HIP(hipGetLastError())
 
-// A cross-stream fork without a marker packet on the producer's queue (round 5).  hipEventRecord behind a kernel costs the
-// stream that carries the chain 1.1 us (2.6 us once another stream really waits on it); an event bound to the kernel's OWN
-// completion signal -- hipExtLaunchKernelGGL(..., stopEvent) -- costs 0.0 / 1.3 us (tools/micro/event_cost.hip: extstop, extfork;
-// profiles/r05/micro_event_cost.txt).  Protocol: the caller arms the event (stop_event_arm), calls a launcher, and records the
-// event the ordinary way if the launcher's kernel did not take it (stop_event_take() != nullptr) -- so a launch path that does
-// not know about stop events stays correct.  Launch sites that honour it use LWS_LAUNCH_STOP instead of hipLaunchKernelGGL.
-// Thread-local: handles are driven from their own host threads (lws_pool).
+// A cross-stream fork without a marker packet on the producer's queue: an event bound to the producer kernel's OWN completion
+// signal -- hipExtLaunchKernelGGL(..., stopEvent) -- instead of hipEventRecord behind it (tools/micro/event_cost.hip;
+// profiles/NOTES.md, "fork cost").  Protocol: a StopArm in the caller's scope arms the event, the caller calls a launcher, and
+// StopArm::finish records the event the ordinary way if the launcher's kernel did not take it -- so a launch path that does not
+// know about stop events stays correct; the guard's destructor disarms on every exit path, so an error return can never leave a
+// stale event armed for the next call on this thread.  Launch sites that honour it use LWS_LAUNCH_STOP instead of
+// hipLaunchKernelGGL.  Thread-local: handles are driven from their own host threads (lws_pool).
+// A kernel-bound event is NOT a capture-time record: under hipGraph capture (use_ext = false) the guard never arms and
+// finish() records the event with hipEventRecord, which is what pulls the waiting stream into the capture.
 extern thread_local hipEvent_t tl_stop_event;
 static inline void stop_event_arm(hipEvent_t e) { tl_stop_event = e; }
 static inline hipEvent_t stop_event_take()
@@ -50,6 +52,25 @@ static inline hipEvent_t stop_event_take()
     tl_stop_event = nullptr;
     return e;
 }
+struct StopArm {
+    hipEvent_t e;
+    hipStream_t st;
+    bool ext;
+    StopArm(hipEvent_t e_, hipStream_t st_, bool use_ext) : e(e_), st(st_), ext(use_ext && e_ != nullptr)
+    {
+        if (ext) stop_event_arm(e);
+    }
+    StopArm(const StopArm &) = delete;
+    StopArm &operator=(const StopArm &) = delete;
+    // after the launcher returned rc: the event must be complete once that kernel is
+    hipError_t finish(int rc)
+    {
+        const bool taken = ext && stop_event_take() == nullptr;      // the launcher's kernel carries it
+        if (e == nullptr || taken || rc != 0) return hipSuccess;
+        return hipEventRecord(e, st);
+    }
+    ~StopArm() { if (ext) (void)stop_event_take(); }
+};
 #define LWS_LAUNCH_STOP(kernel, grid, block, lds, st, ...)                                                  \
     do {                                                                                                    \
         hipEvent_t se_ = ::lws::stop_event_take();                                                          \
@@ -76,8 +97,8 @@ static inline int ensure_dyn_lds(std::atomic<uint64_t> &done, const void *fn, in
 }
 
 // 16-byte activation store.  wt (wave-uniform) selects a write-through store (sc0 sc1): the line does not stay dirty in
-// the XCD's L2, so the end-of-kernel release has less to write back.  Measured r01 on MI355X in k_ref_dws: 12.5 -> 11.7 us
-// per launch at B = 1 (16.8 MB written) but 78.7 -> 95.8 us at B = 8 (134 MB), so launchers enable it for small outputs only.
+// the XCD's L2, so the end-of-kernel release has less to write back.  It pays for small outputs and costs for large ones
+// (profiles/NOTES.md, "write-through stores"), so launchers enable it through use_wt_stores.
 __device__ __forceinline__ void store_act4(float *p, float4 v, int wt)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -142,12 +163,11 @@ struct Conv3dLayer {
 
 struct Stage3d {
     int c3 = 0;
-    int mid8_form = 1;                 // 8 -> 8 layers: 0 = k_conv3d_mid8 (16x16x4, parity rows), 1 = k_conv3d_mid8q (4x4x1_16B)
-    int mid16_form = 0;                // 32 -> 32 layers: 0 = k_conv3d_mid16 (f32 MFMA, the oracle's chain), 1 = k_conv3d_mid16x (split-bf16, not bit-exact)
-    int mid8_tile = 0;                 // 0 = automatic (3x8 or 3x2 rows x 32 by grid size), 1..4 force k_conv3d_mid8q's tile (3x2, 1x4, 3x4, 3x8)
-    int mid8_balance = 1;              // k_conv3d_mid8q on small grids: small tiles with the per-CU residency capped (even spread over the CUs)
+    bool mid8_split = false;           // 8 -> 8 layers: false = k_conv3d_mid8q (4x4x1_16B, the oracle's chain), true = k_conv3d_mid8x (split-bf16, not bit-exact)
+    bool mid16_split = false;          // 32 -> 32 layers: false = k_conv3d_mid16 (f32 MFMA, the oracle's chain), true = k_conv3d_mid16x (split-bf16, not bit-exact)
+    int mid8_balance = 1;              // k_conv3d_mid8q on small grids: the small tile whenever that is the fullest CU's shorter schedule (0 in lws_pool workers)
     int cu_count = 0;                  // compute units of the handle's device (0 = unknown: 256)
-    int dfast = 1;                     // tile order of the stack's kernels: 0 = x, y, d; 1 = d fastest (tile_coords, lws_conv3d.hip)
+    unsigned long long *clk = nullptr; // lws_clock_probe: k_conv3d_mid16 stamps its shader / wall clocks here (64 x 4 values)
     std::vector<Conv3dLayer> layers;   // layers_3d + 2
 };
 
@@ -197,24 +217,14 @@ struct lws_ctx {
     lws_config cfg;
     // schedule options (lws_set_option): every setting computes the same bits, only the launch plan differs
     struct {
-        int left_at = -1;          // refinement1_left on the side stream: 0 = from the start, 2 = beside stages 2-3, -1 = by batch
-        int split_heads = -1;      // right-image feature head on its own stream: -1 = batches >= 4
-        int fuse_shift = 1;        // stage-1 volume inside the first Conv3D launch
-        int fuse_first = 1;        // refinement1_disp's 1 -> 32 convolution inside its first depthwise block
+        int fuse_first = 3;        // bit 0: refinement1_disp's 1 -> 32, bit 1: refinement1_left's 3 -> 32 convolution inside their first depthwise blocks
         int defer_upsample = 1;    // batches <= 2: consumers evaluate the stage-2/3 maps (no k_upsample_add launches)
-        int mid8_form = 1;         // 8 -> 8 Conv3D layers: 0 = k_conv3d_mid8 (16x16x4), 1 = k_conv3d_mid8q (4x4x1_16B, no zero padding)
-        int side_streams = 1;      // 0: no handle-owned side streams, the whole forward on the caller's stream (lws_pool workers)
-        int mid16_form = 0;        // 1: stage-1 middle Conv3D layers on split-bf16 MFMA (k_conv3d_mid16x): float32-level accuracy, NOT bit-exact
-        int conv64_form = 0;       // 1: refinement2[0] (64 -> 32, dilation 8) on split-bf16 MFMA (k_ref_conv64x): NOT bit-exact
-        int conv3d_order = 1;      // tile order of the Conv3D stacks: 0 = x fastest, 1 = d fastest (halo planes shared inside an XCD's L2)
+        int side_streams = 1;      // 0: no handle-owned side stream, the whole forward on the caller's stream (lws_pool workers)
+        int split_bf16 = 0;        // bit mask of the MFMA convolutions on split-bf16 operands (NOT bit-exact): 1 = Conv3D 32 -> 32, 2 = Conv3D 8 -> 8, 4 = refinement2[0]
         int ref_pipe = -1;         // refinement chunks alternating over two streams: -1 = from four chunks up, 0 = never, 1 = from two chunks up
-        int mid8_balance = 1;      // k_conv3d_mid8q: small grids take small tiles with the residency capped so that every CU gets the same number
         int warp_form = 1;         // residual volumes: 1 = right-feature window of a 64-pixel row segment staged in LDS, 0 = every tap gathered from global memory
         int fuse_last1 = 1;        // batches <= 2: stage 1's last Conv3D layer + soft-argmin in one launch, pred1 evaluated by its consumers
-        int mid8_tile = 0;         // force k_conv3d_mid8q's tile shape (see Stage3d); 0 = automatic
         int fork2_after = -1;      // the second fork: 0 = behind stage 1's last Conv3D layer, k = behind its k-th middle layer, -1 = automatic (the last middle layer)
-        int fork_ext = 1;          // the two forks of lws_forward bound to their producer kernel's completion signal (no marker packet)
-        int tail_at = -1;          // feature-extractor tail (conv6, classif1 -> f2): 0 = with conv5 at the first fork (ONE join for f4 and f2), 1 = at the second fork (beside stage 2), 2 = conv5 too at the second fork (no first fork), -1 = automatic (1: measured round 5)
         int fuse_ref_last = -1;    // refinement2's last block + the 32 -> 1 convolution + pred3 in one launch: -1 = batch 1 only, 0 / 1
         int ref_chunk_mb = 72;     // refinement in chunks of pairs whose maps are at most this many MB each (0 = one chunk); see refine_chunk
     } opt;
@@ -239,13 +249,13 @@ struct lws_ctx {
     // activation workspace (grown by lws_reserve / on demand)
     float *ws = nullptr;
     size_t ws_bytes = 0;
-    // side stream for the branch of the forward that depends on the left image only
+    int mid8_balance = 1;                                   // (not an option: lws_pool sets 0 on its workers' clones)
+    // side stream for the branches of the forward that run beside the stage loop (feature tail, refinement1_left)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_feat[3] = {nullptr, nullptr, nullptr};   // f8 / f4 / f2 complete
-    hipStream_t side2 = nullptr;                            // right-image feature layers
-    hipEvent_t ev_right = nullptr;
-    hipEvent_t ev_fork2 = nullptr;                          // second fork of lws_forward (after stage 1's Conv3D stack)
+    hipEvent_t ev_fork2 = nullptr;                          // second fork of lws_forward (beside the end of stage 1's Conv3D stack)
+    unsigned long long *clk_buf = nullptr;                  // lws_clock_probe's device buffer
 };
 
 namespace lws {
@@ -258,12 +268,13 @@ int launch_volume_l1_warp(const float *L, const float *R, const float *prev, flo
                           int B, int C, int h, int w, int H, int W, int m, hipStream_t st, bool q16 = false,
                           const float *plow = nullptr, int ph = 0, int pw = 0, float *pmat = nullptr,     // deferred prev map
                           int form = 1,    // 1 = right-feature window staged in LDS, 0 = every tap gathered from global memory
-                          const float *plow0 = nullptr, int ph0 = 0, int pw0 = 0, float *pmat0 = nullptr);   // prev == nullptr: its own deferred source
+                          const float *plow0 = nullptr, int ph0 = 0, int pw0 = 0, float *pmat0 = nullptr,    // prev == nullptr: its own deferred source
+                          float ioff = 0.5f);   // src_index's offset: 0.5f = interp_align_mode 0, 0.0f = 1 (every `ioff` below)
 int launch_softargmin(const float *cost, float *low, int B, int D, int h, int w, float start, hipStream_t st);
 int launch_upsample_add(const float *low, const float *prev, float *out, int B, int h, int w, int H, int W,
-                        hipStream_t st);
+                        hipStream_t st, float ioff = 0.5f);
 int launch_softargmin_upsample(const float *cost, const float *prev, float *out, float *low_out, int B, int D, int h,
-                               int w, int H, int W, float start, hipStream_t st);
+                               int w, int H, int W, float start, hipStream_t st, float ioff = 0.5f);
 
 // conv3d stack pieces; activations are channels-last [B,D,h,w,C3]
 bool shift_first_can_fuse(const Stage3d &s, int C);
@@ -287,8 +298,9 @@ int launch_conv2d_pair(const Conv2dLayer &a, const Conv2dLayer &b, const float *
 int launch_ref_first(const float *in, int cin, const float *w, float *out, int B, int H, int W, hipStream_t st);
 int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, int W, hipStream_t st);
 bool ref_first_dws_can_fuse(const RefDws &l, int cin);
-int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst, float *out, int B, int H, int W,
-                         hipStream_t st, const float *plow = nullptr, int ph = 0, int pw = 0, float *pmat = nullptr);
+int launch_ref_first_dws(const RefDws &l, const float *img, int cin, const float *wfirst, float *out, int B, int H, int W,
+                         hipStream_t st, const float *plow = nullptr, int ph = 0, int pw = 0, float *pmat = nullptr,
+                         float ioff = 0.5f);
 int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, float *out, int B, int H, int W,
                       hipStream_t st);
 int launch_ref_last(const float *in, const float *w, const float *pred3, float *out, int B, int H, int W, hipStream_t st);

@@ -644,22 +644,25 @@ __device__ __forceinline__ RefTile ref_tile(int dil, int nbx, int nby, int tile_
 // plane strides of 186 / 130 float4 put the 8 planes of one pixel 40 / 8 dwords apart mod 64: conflict-free b128.
 constexpr int DWS_SA = 186, DWS_SB = 130;
 
-// FIRST = true fuses the 1 -> 32 convolution in front of the block (refinement1_disp[0], submodules.py:291-293: 3x3,
-// pad 1, no BN/ReLU) into the staging: `in` is then the [B,1,H,W] disparity map and wf its [tap][32] weights; every
-// halo pixel's 32 channels are recomputed from a dense (RH_Y-1)*dil+3 x (RH_X-1)*dil+3 image window held in LDS
-// (aliased onto sB, which is not live yet) with the same tap-ascending fmaf chain as k_ref_first.  Requires dil = 2.
+// FIRST = CIN > 0 fuses the CIN -> 32 convolution in front of the block (refinement1_disp[0] with CIN = 1, refinement1_left[0]
+// with CIN = 3, submodules.py:282-300: 3x3, pad 1, no BN/ReLU) into the staging: `in` is then the [B,CIN,H,W] image and wf its
+// [tap][cin][32] weights; every halo pixel's 32 channels are recomputed from a dense (RH_Y-1)*dil+3 x (RH_X-1)*dil+3 window of
+// every input plane held in LDS (aliased onto sB, which is not live yet) with the same fmaf chain as k_ref_first -- taps
+// ascending, input channel inner.  Requires dil = 2.  The 32-channel map the separate launch would write and this block read
+// back (128 B per pixel each way) never exists.
 constexpr int DWS_FD = 2, DWS_FR = (RH_Y - 1) * DWS_FD + 3, DWS_FC = (RH_X - 1) * DWS_FD + 3;
-static_assert(DWS_FR * DWS_FC <= 1024 && DWS_FR * DWS_FC <= 8 * DWS_SB * 4, "first-conv window must fit 4 loads/thread and sB");
+static_assert(DWS_FR * DWS_FC <= 1024 && 3 * DWS_FR * DWS_FC <= 8 * DWS_SB * 4, "first-conv window must fit 4 loads/thread/plane and sB");
 
-template <bool FIRST>
+template <int FIRST>
 __global__ __launch_bounds__(256, 4) void k_ref_dws(const float *__restrict__ in, const float *__restrict__ wf,
                                                  const float *__restrict__ bn_s,
                                                  const float *__restrict__ bn_t, const float *dw,   // [tap][32]
                                                  const float4 *pwpk,                              // [q][mt][lane]
                                                  float *__restrict__ out, int H, int W, int dil, int nbx, int nby, int wt,
-                                                 const float *__restrict__ plow, int ph, int pw, float *__restrict__ pmat)
+                                                 const float *__restrict__ plow, int ph, int pw, float *__restrict__ pmat,
+                                                 float ioff)
 {
-    // (FIRST only) plow != nullptr: the disparity map has not been materialised -- it is evaluated on demand as
+    // (FIRST == 1 only) plow != nullptr: the disparity map has not been materialised -- it is evaluated on demand as
     // upsample(plow [ph,pw]) + in (DeferredMap) and this workgroup writes its own tile pixels of it to pmat (the
     // phase-grid tiles of all workgroups partition the image, so the map is written exactly once)
     __shared__ float4 sA[8 * DWS_SA];
@@ -676,10 +679,66 @@ __global__ __launch_bounds__(256, 4) void k_ref_dws(const float *__restrict__ in
     constexpr int NPX = RH_Y * RH_X, SITER = (NPX * 8 + 255) / 256;
     float4 c[SITER];
     bool okv[SITER];
-    if (FIRST) {
+    if (FIRST == 3) {
+        // three input planes: the windows go to sImg[ci][DWS_FR * DWS_FC], all loads of a thread in flight together
         float *sImg = reinterpret_cast<float *>(sB);
-        const DeferredMap dm{plow != nullptr ? plow + (int64_t)t.b * ph * pw : nullptr, in + (int64_t)t.b * H * W, ph, pw,
-                             (float)H, 1.0f / (float)(ph > 0 ? ph : 1)};
+        constexpr int WIN = DWS_FR * DWS_FC, NLD = (3 * WIN + 255) / 256;
+        const float *inb = in + (int64_t)t.b * 3 * H * W;
+        const int gy0 = t.Y0 - DWS_FD - 1, gx0 = t.X0 - DWS_FD - 1;
+        float iv[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int r3 = tid + 256 * k;
+            const int ci = r3 / WIN, r = r3 - ci * WIN;
+            const int ry = r / DWS_FC, rx = r - ry * DWS_FC;
+            const int gy = gy0 + ry, gx = gx0 + rx;
+            const bool ok = r3 < 3 * WIN && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float ld = inb[ok ? (int64_t)ci * H * W + (int64_t)gy * W + gx : 0];
+            iv[k] = ok ? ld : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            if (tid + 256 * k < 3 * WIN) sImg[tid + 256 * k] = iv[k];
+        __syncthreads();
+        // the 32 channels of every halo pixel: one accumulator per item, the tap rows walked in an outer loop that is NOT
+        // unrolled, so that only one row of weights (3 kw x 3 ci float4) is live at a time; chain = (kh, kw) ascending, ci inner
+        float4 a[SITER];
+        const float *sp[SITER];
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int hp = (tid >> 3) + 32 * i;
+            const int hy = hp / RH_X, hx = hp - hy * RH_X;
+            sp[i] = sImg + (hp < NPX ? (hy * DWS_FD) * DWS_FC + hx * DWS_FD : 0);
+            a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+            float4 wq[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) wq[j] = *reinterpret_cast<const float4 *>(wf + (kh * 9 + j) * 32 + c4 * 4);   // [kw][ci]
+#pragma unroll
+            for (int i = 0; i < SITER; ++i)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) fma4s(a[i], sp[i][ci * WIN + kh * DWS_FC + kw], wq[kw * 3 + ci]);
+        }
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int hp = (tid >> 3) + 32 * i;
+            const int hy = hp / RH_X, hx = hp - hy * RH_X;
+            const int gy = t.Y0 + (hy - 1) * DWS_FD, gx = t.X0 + (hx - 1) * DWS_FD;
+            const bool ok = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            float4 v = bn_relu4(a[i], s4, t4);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp < NPX) sA[c4 * DWS_SA + hp] = v;
+        }
+        __syncthreads();          // sImg (= sB) is dead from here; sA is complete
+    } else if (FIRST == 1) {
+        float *sImg = reinterpret_cast<float *>(sB);
+        DeferredMap dm{plow != nullptr ? plow + (int64_t)t.b * ph * pw : nullptr, in + (int64_t)t.b * H * W, ph, pw,
+                       (float)H, 1.0f / (float)(ph > 0 ? ph : 1)};
+        dm.off = ioff;
         const int gy0 = t.Y0 - DWS_FD - 1, gx0 = t.X0 - DWS_FD - 1;
         float iv[4];
         bool iok[4];
@@ -749,7 +808,7 @@ __global__ __launch_bounds__(256, 4) void k_ref_dws(const float *__restrict__ in
     float4 wd[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) wd[tap] = *reinterpret_cast<const float4 *>(dw + tap * 32 + c4 * 4);
-    if (!FIRST) {
+    if (FIRST == 0) {
 #pragma unroll
         for (int i = 0; i < SITER; ++i) {
             const int hp = (tid >> 3) + 32 * i;
@@ -965,7 +1024,7 @@ __global__ __launch_bounds__(64 * NW) void k_ref_conv64(const float *__restrict_
 }
 
 // =============================================================================================
-// refinement2[0], split-bf16 form (k_ref_conv64x; option "conv64_form" = 1, NOT the default and never what bench.py's
+// refinement2[0], split-bf16 form (k_ref_conv64x; option "split_bf16" bit 2, NOT the default and never what bench.py's
 // headline measures: like k_conv3d_mid16x it is not bit-exact against the oracle chain, see lws_conv3d.hip).
 // Same tile and interface as k_ref_conv64.  The BN + ReLU'd halo pixels are split into hi / mid / lo bf16 while they are
 // staged ([tensor][halo pixel][variant][32 channels] bf16, 208-byte pixel stride); one step = (tap, tensor) contracts 32
@@ -1349,28 +1408,37 @@ int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, i
 {
     const int nbx = cdiv(W, RT_X * l.dil), nby = cdiv(H, RT_Y * l.dil);
     dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
-    hipLaunchKernelGGL(k_ref_dws<false>, grid, block, 0, st, in, (const float *)nullptr, l.bn_s, l.bn_t, l.dw,
+    hipLaunchKernelGGL(k_ref_dws<0>, grid, block, 0, st, in, (const float *)nullptr, l.bn_s, l.bn_t, l.dw,
                        reinterpret_cast<const float4 *>(l.pw), out, H, W, l.dil, nbx, nby,
-                       use_wt_stores((size_t)B * H * W * 128), (const float *)nullptr, 0, 0, (float *)nullptr);
+                       use_wt_stores((size_t)B * H * W * 128), (const float *)nullptr, 0, 0, (float *)nullptr, 0.5f);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
 
-// 1 -> 32 first convolution + the first depthwise-separable block in one launch (disparity branch of refinement1)
-bool ref_first_dws_can_fuse(const RefDws &l, int cin) { return cin == 1 && l.dil == DWS_FD; }
+// CIN -> 32 first convolution + the first depthwise-separable block in one launch (refinement1_disp: cin = 1, on a map that may
+// be deferred; refinement1_left: cin = 3)
+bool ref_first_dws_can_fuse(const RefDws &l, int cin) { return (cin == 1 || cin == 3) && l.dil == DWS_FD; }
 
-int launch_ref_first_dws(const RefDws &l, const float *img, const float *wfirst, float *out, int B, int H, int W,
-                         hipStream_t st, const float *plow, int ph, int pw, float *pmat)
+int launch_ref_first_dws(const RefDws &l, const float *img, int cin, const float *wfirst, float *out, int B, int H, int W,
+                         hipStream_t st, const float *plow, int ph, int pw, float *pmat, float ioff)
 {
-    if (!ref_first_dws_can_fuse(l, 1)) {
-        set_error("ref_first_dws: dilation %d unsupported", l.dil);
+    if (!ref_first_dws_can_fuse(l, cin)) {
+        set_error("ref_first_dws: cin %d / dilation %d unsupported", cin, l.dil);
+        return LWS_ERR_INVALID;
+    }
+    if (cin != 1 && (plow != nullptr || pmat != nullptr)) {
+        set_error("ref_first_dws: only the one-channel (disparity) input can be a deferred map");
         return LWS_ERR_INVALID;
     }
     const int nbx = cdiv(W, RT_X * l.dil), nby = cdiv(H, RT_Y * l.dil);
     dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
-    hipLaunchKernelGGL(k_ref_dws<true>, grid, block, 0, st, img, wfirst, l.bn_s, l.bn_t, l.dw,
-                       reinterpret_cast<const float4 *>(l.pw), out, H, W, l.dil, nbx, nby,
-                       use_wt_stores((size_t)B * H * W * 128), plow, ph, pw, pmat);
+    const int wt = use_wt_stores((size_t)B * H * W * 128);
+    if (cin == 3)
+        hipLaunchKernelGGL(k_ref_dws<3>, grid, block, 0, st, img, wfirst, l.bn_s, l.bn_t, l.dw, reinterpret_cast<const float4 *>(l.pw),
+                           out, H, W, l.dil, nbx, nby, wt, (const float *)nullptr, 0, 0, (float *)nullptr, ioff);
+    else
+        hipLaunchKernelGGL(k_ref_dws<1>, grid, block, 0, st, img, wfirst, l.bn_s, l.bn_t, l.dw, reinterpret_cast<const float4 *>(l.pw),
+                           out, H, W, l.dil, nbx, nby, wt, plow, ph, pw, pmat, ioff);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }

@@ -12,7 +12,6 @@
 //
 //   k_conv3d_first8 / k_conv3d_first16   cin = 1 -> C3   fp32 MFMA (K = 27 taps)
 //   k_conv3d_mid16  C3 % 16 == 0     fp32 MFMA implicit GEMM, M = cout tile, N = 16 voxels along x
-//   k_conv3d_mid8   C3 == 8          fp32 MFMA, M = (x parity, cout) so that all 16 MFMA rows work
 //   k_conv3d_mid8q  C3 == 8          v_mfma_f32_4x4x1_16B_f32 with A-block broadcast: 4 couts x 64 voxels, no padding
 //   k_conv3d_last   C3 -> 1 + skip   VALU (K = 27*C3)
 #include <hip/hip_ext.h>
@@ -29,23 +28,16 @@ LWS_DEFINE_STAMPS(conv3d)
 
 __device__ __forceinline__ float bn_relu(float x, float s, float t) { return fmaxf(fmaf(x, s, t), 0.0f); }
 
-// tile index (already XCD-contiguous, xcd_tile) -> tile coordinates.  dfast == 0: x fastest, then y, then d.  dfast != 0: d
-// fastest, then x, then y -- the tiles that share halo planes along d (2 of the 5 planes a 3-deep tile reads) and along y
-// are then neighbours in an XCD's run and co-resident, so their re-reads hit that XCD's L2 instead of the fabric.
-// The same map in every layer of a stack: a consumer tile finds its producer's output in the same L2.  Speed only.
-__device__ __forceinline__ void tile_coords(int tile, int tiles_x, int tiles_y, int tiles_d, int dfast, int &tx, int &ty, int &td)
+// tile index (already XCD-contiguous, xcd_tile) -> tile coordinates: d fastest, then x, then y -- the tiles that share halo
+// planes along d (2 of the 5 planes a 3-deep tile reads) and along y are then neighbours in an XCD's run and co-resident, so
+// their re-reads hit that XCD's L2 instead of the fabric.  The same map in every layer of a stack: a consumer tile finds its
+// producer's output in the same L2.  Speed only.
+__device__ __forceinline__ void tile_coords(int tile, int tiles_x, int tiles_d, int &tx, int &ty, int &td)
 {
-    if (dfast) {
-        td = tile % tiles_d;
-        tile /= tiles_d;
-        tx = tile % tiles_x;
-        ty = tile / tiles_x;
-    } else {
-        tx = tile % tiles_x;
-        tile /= tiles_x;
-        ty = tile % tiles_y;
-        td = tile / tiles_y;
-    }
+    td = tile % tiles_d;
+    tile /= tiles_d;
+    tx = tile % tiles_x;
+    ty = tile / tiles_x;
 }
 
 // compile-time component select (j is always a constant after unrolling)
@@ -100,8 +92,15 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
                                                               const float *__restrict__ bn_s,   // next layer BN [C3]
                                                               const float *__restrict__ bn_t,
                                                               float *__restrict__ out, int D, int h, int w,
-                                                              int tiles_x, int tiles_y, int wt, int tord)
+                                                              int tiles_x, int tiles_y, int wt, int tiles_d,
+                                                              unsigned long long *__restrict__ clk)
 {
+    // clk != nullptr (lws_clock_probe only; kernel-uniform, so a scalar branch): the first 64 workgroups leave the shader-clock
+    // counter (s_memtime) and the 100 MHz wall clock (s_memrealtime) of their first and last instruction -- the clock this
+    // kernel really ran at is d s_memtime / d s_memrealtime x 100 MHz (bench.py: roofline.clock_ghz)
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (clk != nullptr)
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_c0), "=s"(clk_r0)::"memory");
     using Cfg = Mid16Cfg<C3, TD, TY, WR, WM>;
     constexpr int MT = Cfg::MT, Q = Cfg::Q, RW = Cfg::RW, MTW = Cfg::MTW, HY = Cfg::HY, HX = Cfg::HX, VS = Cfg::VS;
     constexpr int NT = Cfg::NT, SITER = Cfg::SITER;
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
     const int wr = wave / WM, wm = wave % WM;     // this wave's row group / output-channel group
     const int n = lane & 15, g = lane >> 4;
     int tx, ty, td;
-    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_d, tx, ty, td);
     const int b = blockIdx.y;
     const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * C3;
@@ -303,10 +302,21 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
         }
     }
     LWS_STAMPK(1, 3);
+    if (clk != nullptr) {
+        unsigned long long c1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+        const unsigned bid = blockIdx.x + gridDim.x * blockIdx.y;
+        if (threadIdx.x == 0 && bid < 64) {
+            clk[4 * bid + 0] = clk_c0;
+            clk[4 * bid + 1] = clk_r0;
+            clk[4 * bid + 2] = c1;
+            clk[4 * bid + 3] = r1;
+        }
+    }
 }
 
 // =============================================================================================
-// Middle layers, C3 == 32, split-bf16 form (k_conv3d_mid16x; option "mid16_form" = 1, NOT the default and never what
+// Middle layers, C3 == 32, split-bf16 form (k_conv3d_mid16x; option "split_bf16" bit 0, NOT the default and never what
 // bench.py's headline measures: it is not bit-exact against the oracle chain).
 //
 // The f32-input MFMA runs at the float32 vector rate (157 TF); the bf16 MFMA at 16x that.  Every float32 operand is split
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid16x(const float *__restrict__
                                                        const float *__restrict__ bn_s,    // next layer BN [32]
                                                        const float *__restrict__ bn_t,
                                                        float *__restrict__ out, int D, int h, int w,
-                                                       int tiles_x, int tiles_y, int tord)
+                                                       int tiles_x, int tiles_y, int tiles_d)
 {
     using Cfg = Mid16xCfg<TD, TY>;
     constexpr int C3 = 32, MT = 2, RW = Cfg::RW, HY = Cfg::HY, HX = Cfg::HX, VSB = Cfg::VSB, NT = Cfg::NT, SITER = Cfg::SITER;
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid16x(const float *__restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     int tx, ty, td;
-    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_d, tx, ty, td);
     const int b = blockIdx.y;
     const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * C3;
@@ -512,164 +522,17 @@ __global__ __launch_bounds__(256) void k_conv3d_mid16x(const float *__restrict__
 }
 
 // =============================================================================================
-// Middle layers, C3 == 8 (stages 2 and 3).
-//
-// With only 8 output channels a 16-row MFMA tile would be half empty.  Instead the 16 rows are
-// (x parity, cout): row i = 8*xpar + cout, column n = voxel pair, output x = x0 + 2n + xpar.  Both
-// parities read the SAME activation x_in = x0 + 2n + t - 1 (t = 0..3), so the B operand is shared and the
-// A operand is W[cout][cin][kd][kh][kw = t - xpar] (zero where t - xpar is outside 0..2: fmaf(0, b, acc)
-// == acc, the chain is unchanged).  K per (kd,kh) is 4 t x 8 cin = 8 MFMAs instead of 3 x 8 / 4 = 6 for
-// half the outputs: 75 % of the MFMA work is useful instead of 50 %.
-// The 72 A fragments (one VGPR each) of a layer stay in registers for the whole kernel; activations are
-// staged in LDS as 8 channel planes [cin][row][34] with an odd plane stride (ds_read_b32 of lanes
-// (g in {0,1}, n) hits 32 different banks).
-// =============================================================================================
-template <int TD, int TY>
-struct Mid8Cfg {
-    static constexpr int ROWS = TD * TY;
-    static constexpr int RW = ROWS / 4;
-    static constexpr int HD = TD + 2, HY = TY + 2, HX = 34;
-    static constexpr int NVOX = HD * HY * HX;
-    static constexpr int PS = (NVOX % 2 == 0) ? NVOX + 1 : NVOX;   // odd plane stride
-    static constexpr int LDS_BYTES = 8 * PS * 4;
-    static_assert(ROWS % 4 == 0, "rows must split over 4 waves");
-};
-
-template <int TD, int TY>
-__global__ __launch_bounds__(256) void k_conv3d_mid8(const float *__restrict__ in,      // [B,D,h,w,8]
-                                                     const float *__restrict__ wpk,     // [18][64][4] A fragments
-                                                     const float *__restrict__ bn_s,    // next layer BN [8]
-                                                     const float *__restrict__ bn_t,
-                                                     float *__restrict__ out, int D, int h, int w,
-                                                     int tiles_x, int tiles_y, int wt, int tord)
-{
-    using Cfg = Mid8Cfg<TD, TY>;
-    constexpr int RW = Cfg::RW, HY = Cfg::HY, HX = Cfg::HX, PS = Cfg::PS;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 15, g = lane >> 4;
-    int tx, ty, td;
-    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
-    const int b = blockIdx.y;
-    const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
-    const float *inb = in + (int64_t)b * D * h * w * 8;
-    LWS_STAMPK(2, 0);
-
-    // next layer's BatchNorm of this lane's 4 output channels (needed only by the epilogue; loaded early)
-    const int xpar = g >> 1, cb = 4 * (g & 1);
-    const float4 es8 = *reinterpret_cast<const float4 *>(bn_s + cb);
-    const float4 et8 = *reinterpret_cast<const float4 *>(bn_t + cb);
-
-    // 72 A fragments of this lane as 18 float4 ([step/4][lane][4]): 18 wide loads instead of 72 dword loads
-    float wa[72];
-#pragma unroll
-    for (int s4 = 0; s4 < 18; ++s4) {
-        const float4 v = reinterpret_cast<const float4 *>(wpk)[s4 * 64 + lane];
-        wa[4 * s4 + 0] = v.x;
-        wa[4 * s4 + 1] = v.y;
-        wa[4 * s4 + 2] = v.z;
-        wa[4 * s4 + 3] = v.w;
-    }
-
-    // ---- stage: one item = half a voxel (4 channels, 16 B); scatter into 4 channel planes.  Static trip count:
-    //      all global loads of a thread are issued before the first LDS write (one memory round trip, not SITER).
-    //      Two phases as in k_conv3d_mid16: iterations i < P1 cover halo slices [0, TD) (all the kd = 0 taps read);
-    //      the rest is written to LDS after the kd = 0 taps.
-    constexpr int ITEMS = Cfg::NVOX * 2, SITER = (ITEMS + 255) / 256;
-    constexpr int P1 = (TD * HY * HX * 2 + 255) / 256 < SITER ? (TD * HY * HX * 2 + 255) / 256 : SITER;
-    float4 c[SITER];
-    bool okv[SITER];
-#pragma unroll
-    for (int i = 0; i < SITER; ++i) {
-        const int it = tid + i * 256;
-        const int half = it & 1, v = it >> 1;
-        const int hx = v % HX, t2 = v / HX, hy = t2 % HY, hd = t2 / HY;
-        const int gd = d0 + hd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        okv[i] = it < ITEMS && gd >= 0 && gd < D && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        c[i] = *reinterpret_cast<const float4 *>(inb + (okv[i] ? (((int64_t)gd * h + gy) * w + gx) * 8 + half * 4 : 0));
-    }
-    auto stage_write = [&](int i) {
-        const int it = tid + i * 256;
-        if (it < ITEMS) {
-            const float4 v4 = okv[i] ? c[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            float *dst = lds + ((it & 1) * 4) * PS + (it >> 1);
-            dst[0] = v4.x;
-            dst[PS] = v4.y;
-            dst[2 * PS] = v4.z;
-            dst[3 * PS] = v4.w;
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < P1; ++i) stage_write(i);
-    __syncthreads();
-    LWS_STAMPK(2, 1);
-
-    floatx4 acc[RW];
-    int rbase[RW];
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        acc[r] = (floatx4){0.f, 0.f, 0.f, 0.f};
-        const int row = wave * RW + r;
-        const int rd = row / TY, ry = row % TY;
-        rbase[r] = g * PS + (rd * HY + ry) * HX + 2 * n;
-    }
-
-#pragma unroll
-    for (int kd = 0; kd < 3; ++kd) {
-        if (kd == 1 && P1 < SITER) {
-#pragma unroll
-            for (int i = P1; i < SITER; ++i) stage_write(i);
-            __syncthreads();
-        }
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int step = ((kd * 3 + kh) * 4 + t) * 2 + half;
-                    const int off = half * 4 * PS + (kd * HY + kh) * HX + t;
-#pragma unroll
-                    for (int r = 0; r < RW; ++r) {
-                        const float bv = lds[rbase[r] + off];
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[step], bv, acc[r], 0, 0, 0);
-                    }
-                }
-    }
-
-    LWS_STAMPK(2, 2);
-    // ---- epilogue: row i = 4*(lane>>4) + reg -> xpar = (lane>>4)>>1, cout = 4*((lane>>4)&1) + reg ----
-    float *outb = out + (int64_t)b * D * h * w * 8;
-    const int gx = x0 + 2 * n + xpar;
-    const float4 s = es8, t = et8;
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        const int row = wave * RW + r;
-        const int gd = d0 + row / TY, gy = y0 + row % TY;
-        if (gd < D && gy < h && gx < w) {
-            float4 v;
-            v.x = bn_relu(acc[r][0], s.x, t.x);
-            v.y = bn_relu(acc[r][1], s.y, t.y);
-            v.z = bn_relu(acc[r][2], s.z, t.z);
-            v.w = bn_relu(acc[r][3], s.w, t.w);
-            store_act4(outb + (((int64_t)gd * h + gy) * w + gx) * 8 + cb, v, wt);
-        }
-    }
-    LWS_STAMPK(2, 3);
-}
-
-// =============================================================================================
-// Middle layers, C3 == 8, split-bf16 form (k_conv3d_mid8x; option "mid8_form" = 2, NOT the default and never what bench.py's
+// Middle layers, C3 == 8, split-bf16 form (k_conv3d_mid8x; option "split_bf16" bit 1, NOT the default and never what bench.py's
 // headline measures: not bit-exact against the oracle chain, see k_conv3d_mid16x).
-// The parity-row tile of k_conv3d_mid8 -- row i = 8 xpar + cout, column n = voxel pair, output x = x0 + 2 n + xpar -- with
+// A parity-row tile -- MFMA row i = 8 xpar + cout, column n = voxel pair, output x = x0 + 2 n + xpar (both parities read the
+// same activations, so all 16 rows of the 8-channel layer work; the scheme k_conv3d_first8 uses with one input channel) -- with
 // K = 32 = 4 x-offsets t x 8 input channels: ONE v_mfma_f32_16x16x32_bf16 contracts a whole (kd, kh) row of taps, lane
 // (n, g) supplying the 8 channels of voxel x0 + 2 n + g - 1 (one ds_read_b128 per variant) against
 // W[cout][cin][kd][kh][g - xpar] (zero where g - xpar is outside 0..2).  9 steps x 6 cross products = 54 MFMAs of 16 cycles
 // per row of 32 outputs, against 216 x 10 cycles on the 4x4x1 form.  LDS: three variant planes [voxel][8 x bf16] with the
 // 16-byte voxel slots XOR-swizzled by bit 4 of the voxel index, so that the 16 lanes of a ds_read_b128 (voxels c, c + 2, ...,
 // c + 30) cover 16 different slots mod 256 B for every c.  Weights pre-split on the host ([step][variant][lane][8]) and
-// streamed two steps ahead; staging in two phases and epilogue as k_conv3d_mid8.
+// streamed two steps ahead; staging in two phases.
 // =============================================================================================
 template <int TD, int TY>
 struct Mid8xCfg {
@@ -693,7 +556,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8x(const float *__restrict__ 
                                                       const float *__restrict__ bn_s,    // next layer BN [8]
                                                       const float *__restrict__ bn_t,
                                                       float *__restrict__ out, int D, int h, int w,
-                                                      int tiles_x, int tiles_y, int tord)
+                                                      int tiles_x, int tiles_y, int tiles_d)
 {
     using Cfg = Mid8xCfg<TD, TY>;
     constexpr int RW = Cfg::RW, HY = Cfg::HY, HX = Cfg::HX, NT = Cfg::NT, SITER = Cfg::SITER, PLANE = Cfg::PLANE;
@@ -703,7 +566,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8x(const float *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     int tx, ty, td;
-    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_d, tx, ty, td);
     const int b = blockIdx.y;
     const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * 8;
@@ -810,7 +673,7 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8x(const float *__restrict__ 
     }
 
     LWS_STAMPK(20, 2);
-    // ---- epilogue (as k_conv3d_mid8): row i = 4*(lane>>4) + reg -> xpar = (lane>>4)>>1, cout = 4*((lane>>4)&1) + reg
+    // ---- epilogue: row i = 4*(lane>>4) + reg -> xpar = (lane>>4)>>1, cout = 4*((lane>>4)&1) + reg
     float *outb = out + (int64_t)b * D * h * w * 8;
     const int gx = x0 + 2 * n + xpar;
 #pragma unroll
@@ -830,17 +693,18 @@ __global__ __launch_bounds__(256) void k_conv3d_mid8x(const float *__restrict__ 
 }
 
 // =============================================================================================
-// Middle layers, C3 == 8, on v_mfma_f32_4x4x1_16B_f32 (k_conv3d_mid8q, option "mid8_form" = 1).
+// Middle layers, C3 == 8, on v_mfma_f32_4x4x1_16B_f32 (k_conv3d_mid8q).
 //
-// The 16x16x4 form above pays 25 % of every instruction for structural zeros (two output positions share a 16-row
-// tile, their windows overlap in 2 of 3 taps).  The multi-block MFMA has no such padding: one instruction is 16
+// With 8 output channels a 16x16x4 tile must pair two output positions per 16-row tile and pays 25 % of every instruction for
+// structural zeros (their windows overlap in 2 of 3 taps; that form, k_conv3d_mid8, was superseded in round 3 and removed in
+// round 6).  The multi-block MFMA has no such padding: one instruction is 16
 // independent 4x4 outer products with K = 1,  D_b[i][j] += A_b[i] * B_b[j]  (b = block = lane / 4), and with the A-block
 // broadcast (CBSZ = 4, ABID = k) all 16 blocks take block k's A.  So
 //     lane l = voxel l of a 64-voxel group (2 rows x 32 along x)  ->  B operand = ONE activation value per lane,
 //     A = W[4 cg .. 4 cg + 3][cin][tap] held by lanes 4k .. 4k+3 of a register, k = 2 cin + cg,
 //     D register i of lane l = output channel 4 cg + i of voxel l:
 // one instruction = 4 output channels x 64 voxels x 1 (tap, cin) term, every FLOP useful, and ONE register holds all
-// 16 (cin, cg) weight blocks of a tap -- 27 A registers for the whole layer instead of 72.  The chain per output is the
+// 16 (cin, cg) weight blocks of a tap -- 27 A registers for the whole layer.  The chain per output is the
 // contract's: taps (kd,kh,kw) outer, cin ascending, one fma each (K = 1).
 // Wave = one 64-voxel group, two accumulators (cout 0-3, 4-7); workgroup = TD x TY x 32 voxels = TD*TY/2 waves; the
 // halo tile sits in LDS channels-last as two half-planes [cin half][voxel] of float4 (one ds_read_b128 at lane base +
@@ -871,7 +735,7 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
                                                                         const float *__restrict__ bn_s,    // next layer BN [8]
                                                                         const float *__restrict__ bn_t,
                                                                         float *__restrict__ out, int D, int h, int w,
-                                                                        int tiles_x, int tiles_y, int wt, int tord)
+                                                                        int tiles_x, int tiles_y, int wt, int tiles_d)
 {
     using Cfg = Mid8qCfg<TD, TY>;
     constexpr int HY = Cfg::HY, HX = Cfg::HX, NP = Cfg::NP;
@@ -880,7 +744,7 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tx, ty, td;
-    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_d, tx, ty, td);
     const int b = blockIdx.y;
     const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
     const float *inb = in + (int64_t)b * D * h * w * 8;
@@ -982,7 +846,7 @@ __global__ __launch_bounds__((Mid8qCfg<TD, TY>::NT)) void k_conv3d_mid8q(const f
 #undef LWS_Q2
 
 // =============================================================================================
-// First layer, C3 == 8 (stages 2 and 3), on fp32 MFMA: k_conv3d_mid8's scheme with one input channel.  Rows =
+// First layer, C3 == 8 (stages 2 and 3), on fp32 MFMA: the parity-row scheme with one input channel.  Rows =
 // (x parity, cout), columns = voxel pairs, K = the four x positions t = 0..3 both parities read, so each (kd,kh) is ONE
 // MFMA whose A operand is W[cout][kd][kh][t - xpar] (zero outside 0..2) and whose B operand is one ds_read_b32 of the
 // BN0+ReLU'd cost halo tile: 9 MFMAs per row of 32 voxels, taps ascending -- the same chain as k_conv3d_first, which
@@ -994,7 +858,7 @@ __global__ __launch_bounds__(256) void k_conv3d_first8(const float *__restrict__
                                                        const float *__restrict__ bn0_s, const float *__restrict__ bn0_t,
                                                        const float *__restrict__ bn_s,    // next layer BN [8]
                                                        const float *__restrict__ bn_t, float *__restrict__ out, int D,
-                                                       int h, int w, int tiles_x, int tiles_y, int tord)
+                                                       int h, int w, int tiles_x, int tiles_y, int tiles_d)
 {
     constexpr int RW = TD * TY / 4, HD = TD + 2, HY = TY + 2, HX = 34, NVOX = HD * HY * HX, SITER = (NVOX + 255) / 256;
     static_assert(TD * TY % 4 == 0, "rows must split over 4 waves");
@@ -1002,7 +866,7 @@ __global__ __launch_bounds__(256) void k_conv3d_first8(const float *__restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     int tx, ty, td;
-    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_d, tx, ty, td);
     const int b = blockIdx.y;
     const int x0 = tx * 32, y0 = ty * TY, d0 = td * TD;
     const float *cb = cost + (int64_t)b * D * h * w;
@@ -1080,7 +944,7 @@ __global__ __launch_bounds__(256) void k_conv3d_first16(float *__restrict__ cost
                                                         const float *__restrict__ bn0_s, const float *__restrict__ bn0_t,
                                                         const float *__restrict__ bn_s,    // next layer BN [C3]
                                                         const float *__restrict__ bn_t, float *__restrict__ out, int D,
-                                                        int h, int w, int tiles_x, int tiles_y, int tord)
+                                                        int h, int w, int tiles_x, int tiles_y, int tiles_d)
 {
     constexpr int MT = C3 / 16, RW = TD * TY / 4, HD = TD + 2, HY = TY + 2, HX = 18, NVOX = HD * HY * HX,
                   SITER = (NVOX + 255) / 256;
@@ -1089,7 +953,7 @@ __global__ __launch_bounds__(256) void k_conv3d_first16(float *__restrict__ cost
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     int tx, ty, td;
-    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx, ty, td);
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_d, tx, ty, td);
     const int b = blockIdx.y;
     const int x0 = tx * 16, y0 = ty * TY, d0 = td * TD;
     float *cb = cost + (int64_t)b * D * h * w;
@@ -1257,14 +1121,14 @@ template <int C3, int TD, int TY, int TX, bool FUSE>
 __global__ __launch_bounds__((LastCfg<C3, TD, TY, TX, FUSE>::NT)) void k_conv3d_last(
     const float *__restrict__ act, const float *__restrict__ wgt,   // [27][C3]
     const float *__restrict__ skip, float *__restrict__ cost_out,  // may be nullptr when FUSE
-    float *__restrict__ low, float start, int D, int h, int w, int tiles_x, int tiles_y, int tord)
+    float *__restrict__ low, float start, int D, int h, int w, int tiles_x, int tiles_y, int tiles_d)
 {
     using Cfg = LastCfg<C3, TD, TY, TX, FUSE>;
     constexpr int HY = Cfg::HY, HX = Cfg::HX, VS = Cfg::VS, NT = Cfg::NT, SITER = Cfg::SITER, C4 = C3 / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     int tx_, ty_, td_;
-    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_y, tord >> 1, tord & 1, tx_, ty_, td_);
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), tiles_x, tiles_d, tx_, ty_, td_);
     const int b = blockIdx.y;
     const int x0 = tx_ * TX, y0 = ty_ * TY, d0 = td_ * TD;
     const int64_t vol = (int64_t)D * h * w;
@@ -1359,10 +1223,9 @@ __global__ __launch_bounds__((LastCfg<C3, TD, TY, TX, FUSE>::NT)) void k_conv3d_
 // =============================================================================================
 // host side
 // =============================================================================================
-constexpr size_t MID8_PACK = 72 * 64;      // k_conv3d_mid8's fragments; k_conv3d_mid8q's 28 x 64 follow
 size_t packed_mid_weight_floats(int c3)
 {
-    if (c3 == 8) return MID8_PACK + 28 * 64 + MID8X_PACK_FLOATS;   // k_conv3d_mid8's, k_conv3d_mid8q's, k_conv3d_mid8x's
+    if (c3 == 8) return 28 * 64 + MID8X_PACK_FLOATS;   // k_conv3d_mid8q's fragments, then k_conv3d_mid8x's
     // 27 taps + two all-zero taps (branch-free two-taps-ahead prefetch in k_conv3d_mid16); C3 == 32: + the split-bf16
     // fragments of k_conv3d_mid16x, 29 taps (two all-zero) x 2 cout tiles x 3 variants x 64 lanes x 8 bf16 = 16 B each
     return (size_t)29 * c3 * c3 + (c3 == 32 ? (size_t)29 * 2 * 3 * 64 * 4 : 0);
@@ -1372,23 +1235,8 @@ size_t packed_mid_weight_floats(int c3)
 void pack_mid_weights(const float *w, int c3, float *out)
 {
     if (c3 == 8) {
-        for (int kd = 0; kd < 3; ++kd)
-            for (int kh = 0; kh < 3; ++kh)
-                for (int t = 0; t < 4; ++t)
-                    for (int half = 0; half < 2; ++half) {
-                        const int step = ((kd * 3 + kh) * 4 + t) * 2 + half;
-                        for (int lane = 0; lane < 64; ++lane) {
-                            const int i = lane & 15, g = lane >> 4;
-                            const int xpar = i >> 3, cout = i & 7;
-                            const int cin = 4 * half + g;
-                            const int kw = t - xpar;
-                            float v = 0.0f;
-                            if (kw >= 0 && kw <= 2) v = w[(cout * 8 + cin) * 27 + (kd * 3 + kh) * 3 + kw];
-                            out[((step >> 2) * 64 + lane) * 4 + (step & 3)] = v;
-                        }
-                    }
         // k_conv3d_mid8q: register `tap`, lane 4 (2 cin + cg) + i  ->  W[4 cg + i][cin][tap]; stored [tap / 4][lane][tap % 4]
-        float *oq = out + MID8_PACK;
+        float *oq = out;
         for (int tap = 0; tap < 28; ++tap)
             for (int lane = 0; lane < 64; ++lane) {
                 const int k = lane >> 2, i = lane & 3, cin = k >> 1, cg = k & 1;
@@ -1396,7 +1244,7 @@ void pack_mid_weights(const float *w, int c3, float *out)
             }
         // k_conv3d_mid8x: lane l of (step = 3 kd + kh, variant) holds W[l & 7][cin = j][kd][kh][kw = (l >> 4) - ((l >> 3) & 1)],
         // j = 0..7, as bf16 bits (zero where kw is outside 0..2); two all-zero steps close the stream
-        uint16_t *ox = reinterpret_cast<uint16_t *>(out + MID8_PACK + 28 * 64);
+        uint16_t *ox = reinterpret_cast<uint16_t *>(out + 28 * 64);
         for (int step = 0; step < 11; ++step)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
@@ -1451,7 +1299,7 @@ int launch_shift_first(const Stage3d &s, const float *L, const float *R, float *
 #define LWS_SF(C3v, SH)                                                                                               \
     hipLaunchKernelGGL((k_conv3d_first16<C3v, TD, TY, SH>), grid, block, 0, st, cost, L, R, s.layers[0].w_mfma,        \
                        s.layers[0].bn_s, s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w,      \
-                       tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0))
+                       tiles_x, tiles_y, tiles_d)
     if (s.c3 == 32) {
         if (q16) LWS_SF(32, 2);
         else LWS_SF(32, 1);
@@ -1473,7 +1321,7 @@ int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int
         dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
         hipLaunchKernelGGL((k_conv3d_first8<TD, TY>), grid, block, 0, st, cost, s.layers[0].w_mfma, s.layers[0].bn_s,
                            s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w, tiles_x, tiles_y,
-                           2 * tiles_d + (s.dfast ? 1 : 0));
+                           tiles_d);
         LWS_LAUNCH_CHECK();
         return LWS_OK;
     }
@@ -1486,11 +1334,11 @@ int launch_conv3d_first(const Stage3d &s, const float *cost, float *act_out, int
         if (s.c3 == 32)
             hipLaunchKernelGGL((k_conv3d_first16<32, TD, TY, 0>), grid, block, 0, st, cin, nofeat, nofeat, s.layers[0].w_mfma,
                                s.layers[0].bn_s, s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w,
-                               tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
+                               tiles_x, tiles_y, tiles_d);
         else
             hipLaunchKernelGGL((k_conv3d_first16<16, TD, TY, 0>), grid, block, 0, st, cin, nofeat, nofeat, s.layers[0].w_mfma,
                                s.layers[0].bn_s, s.layers[0].bn_t, s.layers[1].bn_s, s.layers[1].bn_t, act_out, D, h, w,
-                               tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
+                               tiles_x, tiles_y, tiles_d);
         LWS_LAUNCH_CHECK();
         return LWS_OK;
     }
@@ -1518,11 +1366,11 @@ static int mid16_launch(const Stage3d &s, int layer, const float *in, float *out
         // profiler on: the events carry the kernel's own begin / end timestamps (no dispatch latency in between)
         hipExtLaunchKernelGGL((k_conv3d_mid16<C3, TD, TY, WR, WM>), grid, block, Cfg::LDS_BYTES, st, e0, e1, 0, in,
                               reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
-                              s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt, 2 * tiles_d + (s.dfast ? 1 : 0));
+                              s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt, tiles_d, s.clk);
     } else {
         LWS_LAUNCH_STOP((k_conv3d_mid16<C3, TD, TY, WR, WM>), grid, block, Cfg::LDS_BYTES, st, in,
                         reinterpret_cast<const float4 *>(s.layers[layer].w), s.layers[layer + 1].bn_s,
-                        s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt, 2 * tiles_d + (s.dfast ? 1 : 0));
+                        s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, wt, tiles_d, s.clk);
     }
     LWS_LAUNCH_CHECK();
     return LWS_OK;
@@ -1543,61 +1391,29 @@ static int mid16x_launch(const Stage3d &s, int layer, const float *in, float *ou
     const uint4 *wx = reinterpret_cast<const uint4 *>(s.layers[layer].w + (size_t)29 * 32 * 32);
     if (e0 != nullptr)
         hipExtLaunchKernelGGL((k_conv3d_mid16x<TD, TY>), grid, block, Cfg::LDS_BYTES, st, e0, e1, 0, in, wx, s.layers[layer + 1].bn_s,
-                              s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
+                              s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, tiles_d);
     else
         hipLaunchKernelGGL((k_conv3d_mid16x<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in, wx, s.layers[layer + 1].bn_s,
-                           s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
+                           s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, tiles_d);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
 
-template <int TD, int TY>
-static int mid8_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w,
-                       hipStream_t st)
-{
-    using Cfg = Mid8Cfg<TD, TY>;
-    static std::atomic<uint64_t> attr_done{0};
-    if (Cfg::LDS_BYTES > 48 * 1024) {
-        const int rc_ = ensure_dyn_lds(attr_done, reinterpret_cast<const void *>(&k_conv3d_mid8<TD, TY>), Cfg::LDS_BYTES);
-        if (rc_) return rc_;
-    }
-    const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
-    dim3 grid(tiles_x * tiles_y * tiles_d, B), block(256);
-    hipLaunchKernelGGL((k_conv3d_mid8<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w,
-                       // (write-through stores for outputs <= 40 MB, as k_ref_dws uses them: measured round 5, no change at batch 1
-                       // -- 2,091-2,101 vs 2,096-2,103 pairs/s -- so the stores stay write-back)
-                       s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, /*wt=*/0,
-                       2 * tiles_d + (s.dfast ? 1 : 0));
-    LWS_LAUNCH_CHECK();
-    return LWS_OK;
-}
-
-// wg_per_cu > 0: the launch asks for 160 KB / wg_per_cu of LDS per workgroup instead of what the tile needs, so that at most
-// wg_per_cu workgroups are resident on a CU.  With a grid of at most wg_per_cu x (number of CUs) workgroups every CU then gets
-// the same number of tiles whatever order the dispatcher fills them in (left alone it packed up to four 32.6 KB workgroups on
-// some CUs and two on others: the launch lasted as long as its fullest CU).
 constexpr int kCuLdsBytes = 160 * 1024;
 
 template <int TD, int TY>
-static int mid8q_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w, hipStream_t st,
-                        int wg_per_cu = 0)
+static int mid8q_launch(const Stage3d &s, int layer, const float *in, float *out, int B, int D, int h, int w, hipStream_t st)
 {
     using Cfg = Mid8qCfg<TD, TY>;
     static std::atomic<uint64_t> attr_done{0};
-    int lds = Cfg::LDS_BYTES;
-    // (2 KB under the even share: with exactly 160 KB / 3 per workgroup only two were resident -- allocation granularity)
-    if (wg_per_cu > 1 && (kCuLdsBytes / wg_per_cu - 2048) / 256 * 256 > lds) lds = (kCuLdsBytes / wg_per_cu - 2048) / 256 * 256;
-    if (lds > 48 * 1024) {
+    if (Cfg::LDS_BYTES > 48 * 1024) {
         const int rc_ = ensure_dyn_lds(attr_done, reinterpret_cast<const void *>(&k_conv3d_mid8q<TD, TY>), kCuLdsBytes);
         if (rc_) return rc_;
     }
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
-    hipLaunchKernelGGL((k_conv3d_mid8q<TD, TY>), grid, block, lds, st, in, s.layers[layer].w + MID8_PACK,
-                       // (write-through stores for outputs <= 40 MB, as k_ref_dws uses them: measured round 5, no change at batch 1
-                       // -- 2,091-2,101 vs 2,096-2,103 pairs/s -- so the stores stay write-back)
-                       s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, /*wt=*/0,
-                       2 * tiles_d + (s.dfast ? 1 : 0));
+    hipLaunchKernelGGL((k_conv3d_mid8q<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in, s.layers[layer].w,
+                       s.layers[layer + 1].bn_s, s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, /*wt=*/0, tiles_d);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -1612,8 +1428,8 @@ static int mid8x_launch(const Stage3d &s, int layer, const float *in, float *out
     const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
     hipLaunchKernelGGL((k_conv3d_mid8x<TD, TY>), grid, block, Cfg::LDS_BYTES, st, in,
-                       reinterpret_cast<const uint4 *>(s.layers[layer].w + MID8_PACK + 28 * 64), s.layers[layer + 1].bn_s,
-                       s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
+                       reinterpret_cast<const uint4 *>(s.layers[layer].w + 28 * 64), s.layers[layer + 1].bn_s,
+                       s.layers[layer + 1].bn_t, out, D, h, w, tiles_x, tiles_y, tiles_d);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -1624,66 +1440,28 @@ int launch_conv3d_mid(const Stage3d &s, int layer, const float *act_in, float *a
 {
     switch (s.c3) {
         case 8: {
-            // (whole-D tiles, 9 rows per wave, measured r01: 19.3 vs 17.0 us at B=1 256x512 -- one wave per SIMD cannot
-            // overlap its own staging with its MFMAs, three co-resident small workgroups can)
-            // Measured r03 (tools/sbench.py, one run, us per launch, 16x16x4 parity-row tiles vs 4x4x1_16B): stage 2 (9 x 64 x 128)
-            // 8.7 vs 7.8 at B = 1, 13.4 vs 12.2 at B = 2, 32.5 vs 29.0 at B = 8; stage 3 (9 x 128 x 256) 17.6 vs 15.9, 30.0 vs 28.8,
-            // 105.0 vs 94.8; 8 x 368x1232: 102 vs 85 and 369 vs 328.  (Without the two-phase staging the 4x4x1 form lost at
-            // 8 x 9x64x128 and 2 x 9x128x256: 34.5 and 33.3 us.)
-            // split-bf16 (NOT bit-exact).  Measured r03 (tools/sbench.py, us per launch, 4x4x1 -> split): 8 x 9x128x256 81.8 -> 69.3,
-            // 8 x 9x64x128 24.4 -> 20.5, 1 x 9x128x256 17.3 -> 13.2, but 1 x 9x64x128 (192 tiles) 7.8 -> 8.4: grids that do not
-            // fill the chip stay on the exact kernel (dispatch-bound either way).  Other shapes of the same kernel, 8 x 9x128x256 /
-            // 1 x 9x128x256 / 8 x 9x184x616: 6 waves x 2 rows (142 VGPRs, 3 waves per SIMD) 96.5 / 14.7 / 381 us, 3 x 8 x 32 tiles
-            // with 12 waves 77.2 / 14.7 / 306, this one (4 waves x 3 rows, 188 VGPRs) 70.7 / 12.4 / 272.
-            // (the choice depends on the per-SAMPLE geometry only, never on B: in this mode -- the only one whose two
-            // candidate kernels differ in bits -- a pair must get the same bits at every batch size, so that the sharded /
-            // pooled / batched results stay equal to each other: ADVICE r3)
-            if (s.mid8_form == 2 && (long)cdiv(w, 32) * cdiv(h, 4) * cdiv(D, 3) >= 256)
+            // split-bf16 (NOT bit-exact) only where its grid fills the chip; the choice depends on the per-SAMPLE geometry, never on
+            // B: in this mode -- the only one whose two candidate kernels differ in bits -- a pair must get the same bits at every
+            // batch size, so that the sharded / pooled / batched results stay equal to each other
+            if (s.mid8_split && (long)cdiv(w, 32) * cdiv(h, 4) * cdiv(D, 3) >= 256)
                 return mid8x_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
-            if (s.mid8_form >= 1) {
-                // Tile: 3 x 8 x 32 voxels (12 waves, 54 KB of LDS, halo 2.21x) once there are enough of them to fill the chip,
-                // else 3 x 4 x 32 (6 waves, 32.6 KB, halo 2.66x).  The staging is what bounds this kernel (the CU's fetch path),
-                // so 17 % fewer halo bytes per output are worth more than the smaller tile's occupancy -- measured r03
-                // (tools/sbench.py, one run, us per launch, small -> large tile): 8 x 9x128x256 95.3 -> 81.2 (100 TF useful =
-                // 0.64 of the peak), 8 x 9x64x128 30.4 -> 24.1, 2 x 9x128x256 29.3 -> 23.2, 2 x 9x64x128 12.4 -> 10.7,
-                // 8 x 9x184x616 332 -> 303, 8 x 9x92x308 85.9 -> 78.1; 1 x 9x128x256 (384 large tiles) 16.3 -> 16.3;
-                // 1 x 9x64x128 (96 large tiles) 7.8 -> 9.4: hence the threshold.
-                // Round 4: a launch lasts as long as its fullest CU (the MFMA issue rate of the 4x4x1 form bounds a CU: 5,184
-                // instructions per large tile / 4 SIMDs x 10 cycles).  One 256x512 pair at stage 3 is 384 large tiles on 256 CUs
-                // -- two on half of them, 1,536 voxels -- or 768 small ones, three per CU = 1,152 voxels IF they are spread evenly:
-                // small tiles with the residency capped at ks per CU (mid8q_launch) whenever that is the shorter schedule and
-                // ks <= 4; larger grids balance statistically and take the large tile.
-                const long big_tiles = (long)cdiv(w, 32) * cdiv(h, 8) * cdiv(D, 3) * B;
-                const long small_tiles = (long)cdiv(w, 32) * cdiv(h, 4) * cdiv(D, 3) * B;
-                const long ncu = s.cu_count > 0 ? s.cu_count : 256;
-                const long ks = (small_tiles + ncu - 1) / ncu, kl = (big_tiles + ncu - 1) / ncu;
-                const bool small_wins = s.mid8_balance != 0 && ks <= 4 && ks * 384 < kl * 768;
-                const int cap = (s.mid8_balance != 0 && ks <= 4) ? (int)ks : 0;
-                // (Round 4, built, bit-exact, measured, removed: the same tiles on packed float32 VALU -- v_pk_fma_f32 with the
-                // weights as SGPR pairs, priced at 119-122 TF by tools/micro/pkfma_conv.hip -- ran at 76 TF in place against this
-                // kernel's 100 at 8 x 9x128x256, 43 vs 61 at B = 1: profiles/r04/experiments/sbench_mid8v_packed_valu_form.txt.)
-                // Round 5 ("more, smaller workgroups for the launch-bound layers"): wherever the rule above
-                // picks the small tile, 3 x 2 x 32 voxels (3 waves, 21.8 KB, halo 3.5x, no residency cap) replace 3 x 4 x 32.
-                // Alone the two are equal (tools/sbench.py, one pair: stage 2 8.2 vs 7.8 us, stage 3 16.3 vs 16.6); in the forward,
-                // where these launches run beside refinement1_left's k_ref_dws on the side stream, the smaller workgroups
-                // co-schedule better: 2,088-2,094 vs 2,065-2,070 pairs/s at batch 1 (+1.0 %), both stages contributing (stage 3
-                // only: 2,080).  Forced on grids where the LARGE tile is the automatic choice it loses: 2,555 vs 2,587 at batch 2,
-                // 2,970 vs 3,009 at batch 8, 613 vs 627 at 544x960; 1 x 4 x 32 tiles (2 waves) lose everywhere (2,022-2,026).
-                // profiles/r05/experiments/bench_mid8_tile*.txt, sbench_mid8_tile_b1.txt.  Option "mid8_tile" forces a shape
-                // (1 = 3x2, 2 = 1x4, 3 = 3x4 with round 4's residency cap, 4 = 3x8; t2 + 8 t3 addresses the stages separately).
-                if (s.mid8_tile == 1) return mid8q_launch<3, 2>(s, layer, act_in, act_out, B, D, h, w, st);
-                if (s.mid8_tile == 2) return mid8q_launch<1, 4>(s, layer, act_in, act_out, B, D, h, w, st);
-                if (s.mid8_tile == 3) return mid8q_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st, cap);
-                if (s.mid8_tile == 4) return mid8q_launch<3, 8>(s, layer, act_in, act_out, B, D, h, w, st);
-                if (big_tiles >= 192 && !small_wins) return mid8q_launch<3, 8>(s, layer, act_in, act_out, B, D, h, w, st);
-                return mid8q_launch<3, 2>(s, layer, act_in, act_out, B, D, h, w, st);
-            }
-            return mid8_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st);
+            // k_conv3d_mid8q's tile: 3 x 8 x 32 voxels (12 waves, 54 KB of LDS, halo 2.21x) once there are enough of them to fill
+            // the chip and they balance, else 3 x 2 x 32 (3 waves, 21.8 KB, halo 3.5x).  The staging bounds the kernel, so the
+            // large tile's smaller halo wins wherever the grid is large; a launch lasts as long as its fullest CU, so a grid of
+            // at most four small tiles per CU takes the small tile whenever that is the shorter schedule of the fullest CU
+            // (`mid8_balance`; lws_pool workers run without it: other forwards fill the CUs).  History and numbers:
+            // profiles/NOTES.md, "k_conv3d_mid8q tile choice".
+            const long big_tiles = (long)cdiv(w, 32) * cdiv(h, 8) * cdiv(D, 3) * B;
+            const long small_tiles = (long)cdiv(w, 32) * cdiv(h, 4) * cdiv(D, 3) * B;
+            const long ncu = s.cu_count > 0 ? s.cu_count : 256;
+            const long ks = (small_tiles + ncu - 1) / ncu, kl = (big_tiles + ncu - 1) / ncu;
+            const bool small_wins = s.mid8_balance != 0 && ks <= 4 && ks * 384 < kl * 768;
+            if (big_tiles >= 192 && !small_wins) return mid8q_launch<3, 8>(s, layer, act_in, act_out, B, D, h, w, st);
+            return mid8q_launch<3, 2>(s, layer, act_in, act_out, B, D, h, w, st);
         }
         case 16: return mid16_launch<16, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
         case 32: {
-            if (s.mid16_form == 1) return mid16x_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
-            // (8-wave workgroups <32,3,4,4,2> and half-height tiles <32,3,2,2,2> measured within 1 % of this, r01)
+            if (s.mid16_split) return mid16x_launch<3, 4>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
             return mid16_launch<32, 3, 4, 4, 1>(s, layer, act_in, act_out, B, D, h, w, st, e0, e1);
         }
         default: set_error("conv3d: unsupported channel count %d (8, 16, 32)", s.c3); return LWS_ERR_INVALID;
@@ -1703,7 +1481,7 @@ static int last_launch(const Stage3d &s, const float *act, const float *skip, fl
     const int tiles_x = cdiv(w, TX), tiles_y = cdiv(h, TY), tiles_d = cdiv(D, TD);
     dim3 grid(tiles_x * tiles_y * tiles_d, B), block(Cfg::NT);
     LWS_LAUNCH_STOP((k_conv3d_last<C3, TD, TY, TX, FUSE>), grid, block, Cfg::LDS_BYTES, st, act, s.layers.back().w,
-                    skip, cost_out, low, start, D, h, w, tiles_x, tiles_y, 2 * tiles_d + (s.dfast ? 1 : 0));
+                    skip, cost_out, low, start, D, h, w, tiles_x, tiles_y, tiles_d);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }

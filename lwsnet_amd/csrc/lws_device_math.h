@@ -128,10 +128,14 @@ __device__ __forceinline__ float lws_expf(float x)
     return __int_as_float(bits);
 }
 
-// Half-pixel bilinear source index (F.interpolate align_corners=False, align_mode=0).
-__device__ __forceinline__ void src_index(int dst, float ratio, int in, int &i0, int &i1, float &l0, float &l1)
+// Bilinear source index of F.interpolate(align_corners=False) -- the ONE place every resize of the path gets its taps from
+// (k_volume_l1_warp's prologue, k_upsample_add, k_softargmin_upsample, DeferredMap and through it the fused consumers).
+// `off` carries lws_config.interp_align_mode: 0.5f = align_mode 0, half-pixel centres, src = ratio * (dst + 0.5) - 0.5 (what
+// the oracle bets Paddle 2.0rc0 does); 0.0f = align_mode 1, src = ratio * dst (Paddle 1.x / 2.0-beta) --
+// the same expression, since x + 0 and x - 0 are exact.  /root/reference/models/models.py:119,146,154,161.
+__device__ __forceinline__ void src_index(int dst, float ratio, int in, int &i0, int &i1, float &l0, float &l1, float off)
 {
-    float s = ratio * ((float)dst + 0.5f) - 0.5f;
+    float s = ratio * ((float)dst + off) - off;
     if (s < 0.0f) s = 0.0f;
     int a = (int)s;
     if (a > in - 1) a = in - 1;
@@ -155,20 +159,21 @@ struct DeferredMap {
     const float *low0 = nullptr;   // [h0,w0]: the previous map's own low-resolution source (see above)
     int h0 = 0, w0 = 0;
     float mul_b0 = 0.0f;           // 1/(float)h0
+    float off = 0.5f;              // src_index's offset (lws_config.interp_align_mode)
 };
 
 // upsample(low * mul_a * mul_b) at N points, every load issued before the first use: k_upsample_add's operations
 template <int N>
 __device__ __forceinline__ void upsample_at_n(const float *low, int h, int w, float mul_a, float mul_b, const int (&ys)[N],
-                                              const int (&xs)[N], int H, int W, float (&out)[N])
+                                              const int (&xs)[N], int H, int W, float (&out)[N], float off)
 {
     const float rh = (float)h / (float)H, rw = (float)w / (float)W;
     float hy0[N], hy1[N], wx0[N], wx1[N], t[N][4];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         int y0, y1, x0, x1;
-        src_index(ys[i], rh, h, y0, y1, hy0[i], hy1[i]);
-        src_index(xs[i], rw, w, x0, x1, wx0[i], wx1[i]);
+        src_index(ys[i], rh, h, y0, y1, hy0[i], hy1[i], off);
+        src_index(xs[i], rw, w, x0, x1, wx0[i], wx1[i], off);
         t[i][0] = low[y0 * w + x0];
         t[i][1] = low[y0 * w + x1];
         t[i][2] = low[y1 * w + x0];
@@ -200,7 +205,7 @@ __device__ __forceinline__ void deferred_at_n(const DeferredMap &m, const int (&
 #pragma unroll
         for (int i = 0; i < N; ++i) pv[i] = m.prev[(int64_t)ys[i] * W + xs[i]];
     } else if (m.low0 != nullptr) {
-        upsample_at_n<N>(m.low0, m.h0, m.w0, m.mul_a, m.mul_b0, ys, xs, H, W, pv);
+        upsample_at_n<N>(m.low0, m.h0, m.w0, m.mul_a, m.mul_b0, ys, xs, H, W, pv, m.off);
     } else {
 #pragma unroll
         for (int i = 0; i < N; ++i) pv[i] = 0.0f;
@@ -215,7 +220,7 @@ __device__ __forceinline__ void deferred_at_n(const DeferredMap &m, const int (&
         return;
     }
     float v[N];
-    upsample_at_n<N>(m.low, m.h, m.w, m.mul_a, m.mul_b, ys, xs, H, W, v);
+    upsample_at_n<N>(m.low, m.h, m.w, m.mul_a, m.mul_b, ys, xs, H, W, v, m.off);
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = have_prev ? v[i] + pv[i] : v[i];
 }

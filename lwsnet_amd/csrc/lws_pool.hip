@@ -192,7 +192,7 @@ int lws_pool_create(lws_handle src, int workers, int flags, lws_pool_handle *out
         h->opt.side_streams = (flags & LWS_POOL_SIDE_STREAMS) ? 1 : 0;
         // several forwards share the CUs: no residency cap on k_conv3d_mid8q (a capped workgroup holds a third of a CU's LDS
         // idle, which the kernels of the other workers' forwards could use)
-        h->opt.mid8_balance = 0;
+        h->mid8_balance = 0;
         for (int s_ = 0; s_ < 3; ++s_) h->stage[s_].mid8_balance = 0;
         hipStream_t st = nullptr;
         if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {

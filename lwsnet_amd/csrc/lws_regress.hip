@@ -65,7 +65,7 @@ int launch_softargmin(const float *cost, float *low, int B, int D, int h, int w,
 __global__ __launch_bounds__(256) void k_upsample_add(const float *__restrict__ low,
                                                       const float *__restrict__ prev,
                                                       float *__restrict__ out, int h, int w, int H, int W,
-                                                      float mul_a, float mul_b)
+                                                      float mul_a, float mul_b, float ioff)
 {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void k_upsample_add(const float *__restrict__ 
     const float rh = (float)h / (float)H, rw = (float)w / (float)W;
     int y0, y1, x0, x1;
     float hy0, hy1, wx0, wx1;
-    src_index(y, rh, h, y0, y1, hy0, hy1);
-    src_index(x, rw, w, x0, x1, wx0, wx1);
+    src_index(y, rh, h, y0, y1, hy0, hy1, ioff);
+    src_index(x, rw, w, x0, x1, wx0, wx1, ioff);
     const float *p = low + (int64_t)b * h * w;
     float p00 = (p[(int64_t)y0 * w + x0] * mul_a) * mul_b;
     float p01 = (p[(int64_t)y0 * w + x1] * mul_a) * mul_b;
@@ -90,11 +90,11 @@ __global__ __launch_bounds__(256) void k_upsample_add(const float *__restrict__ 
 }
 
 int launch_upsample_add(const float *low, const float *prev, float *out, int B, int h, int w, int H, int W,
-                        hipStream_t st)
+                        hipStream_t st, float ioff)
 {
     dim3 grid(cdiv(W, 64), cdiv(H, 4), B), block(64, 4);
     hipLaunchKernelGGL(k_upsample_add, grid, block, 0, st, low, prev, out, h, w, H, W, (float)H,
-                       1.0f / (float)h);
+                       1.0f / (float)h, ioff);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }
@@ -109,7 +109,7 @@ template <int DT, int SU_TY, int SU_TX>
 __global__ __launch_bounds__(256) void k_softargmin_upsample(const float *__restrict__ cost,
                                                              const float *__restrict__ prev, float *__restrict__ out,
                                                              float *__restrict__ low_out, int D, int h, int w, int H,
-                                                             int W, float start, float mul_a, float mul_b)
+                                                             int W, float start, float mul_a, float mul_b, float ioff)
 {
     constexpr int SU_HY = SU_TY + 2, SU_HX = SU_TX + 2;
     __shared__ float sLow[SU_HY * SU_HX];
@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256) void k_softargmin_upsample(const float *__rest
         if (y >= H || x >= W) continue;
         int y0, y1, x0, x1;
         float hy0, hy1, wx0, wx1;
-        src_index(y, rh, h, y0, y1, hy0, hy1);
-        src_index(x, rw, w, x0, x1, wx0, wx1);
+        src_index(y, rh, h, y0, y1, hy0, hy1, ioff);
+        src_index(x, rw, w, x0, x1, wx0, wx1, ioff);
         const float *p = sLow + (1 - ly0) * SU_HX + (1 - lx0);      // low-res (y,x) -> sLow[(y-ly0+1)*HX + x-lx0+1]
         float p00 = (p[y0 * SU_HX + x0] * mul_a) * mul_b;
         float p01 = (p[y0 * SU_HX + x1] * mul_a) * mul_b;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_softargmin_upsample(const float *__rest
 }
 
 int launch_softargmin_upsample(const float *cost, const float *prev, float *out, float *low_out, int B, int D, int h,
-                               int w, int H, int W, float start, hipStream_t st)
+                               int w, int H, int W, float start, hipStream_t st, float ioff)
 {
     const bool small = (long)cdiv(w, 8) * cdiv(h, 4) * B < 256;
     dim3 grid(cdiv(w, small ? 4 : 8), cdiv(h, small ? 2 : 4), B), block(256);
@@ -185,10 +185,10 @@ int launch_softargmin_upsample(const float *cost, const float *prev, float *out,
 #define LWS_SU(DT)                                                                                                              \
     if (small)                                                                                                                  \
         hipLaunchKernelGGL((k_softargmin_upsample<DT, 2, 4>), grid, block, 0, st, cost, prev, out, low_out, D, h, w, H, W, start, \
-                           mul_a, mul_b);                                                                                       \
+                           mul_a, mul_b, ioff);                                                                                  \
     else                                                                                                                        \
         hipLaunchKernelGGL((k_softargmin_upsample<DT, 4, 8>), grid, block, 0, st, cost, prev, out, low_out, D, h, w, H, W, start, \
-                           mul_a, mul_b)
+                           mul_a, mul_b, ioff)
     switch (D) {
         case 9: LWS_SU(9); break;
         case 24: LWS_SU(24); break;

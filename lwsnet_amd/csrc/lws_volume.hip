@@ -163,7 +163,7 @@ __global__ __launch_bounds__(WARP_TX *WARP_NW) void k_volume_l1_warp(const float
                                                                       const float *__restrict__ plow, int ph, int pw,
                                                                       float *__restrict__ pmat, int force_gather,
                                                                       const float *__restrict__ plow0, int ph0, int pw0,
-                                                                      float *__restrict__ pmat0)
+                                                                      float *__restrict__ pmat0, float ioff)
 {
     // plow != nullptr: the previous stage's full-resolution map has not been materialised (no k_upsample_add launch):
     // it is evaluated on demand as upsample(plow [ph,pw]) + prev (prev = the map of the stage before it), see
@@ -203,10 +203,11 @@ __global__ __launch_bounds__(WARP_TX *WARP_NW) void k_volume_l1_warp(const float
             const float rh_ = (float)H / (float)h, rw_ = (float)W / (float)w;
             int y0, y1, x0, x1;
             float hy0, hy1, wx0, wx1;
-            src_index(y, rh_, H, y0, y1, hy0, hy1);
-            src_index(x, rw_, W, x0, x1, wx0, wx1);
+            src_index(y, rh_, H, y0, y1, hy0, hy1, ioff);
+            src_index(x, rw_, W, x0, x1, wx0, wx1, ioff);
             DeferredMap dm{plow != nullptr ? plow + (int64_t)b * ph * pw : nullptr,
                            prev != nullptr ? prev + (int64_t)b * H * W : nullptr, ph, pw, (float)H, 1.0f / (float)(ph > 0 ? ph : 1)};
+            dm.off = ioff;
             if (plow0 != nullptr) {
                 dm.low0 = plow0 + (int64_t)b * ph0 * pw0;
                 dm.h0 = ph0;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(WARP_TX *WARP_NW) void k_volume_l1_warp(const float
 
 int launch_volume_l1_warp(const float *L, const float *R, const float *prev, float *cost, float *wflow_out,
                           int B, int C, int h, int w, int H, int W, int m, hipStream_t st, bool q16, const float *plow,
-                          int ph, int pw, float *pmat, int form, const float *plow0, int ph0, int pw0, float *pmat0)
+                          int ph, int pw, float *pmat, int form, const float *plow0, int ph0, int pw0, float *pmat0, float ioff)
 {
     if ((pmat != nullptr || pmat0 != nullptr) && (plow == nullptr || H != 2 * h || W != 2 * w)) {
         set_error("volume_l1_warp: the deferred map can only be written out at exactly half resolution");
@@ -396,10 +397,10 @@ int launch_volume_l1_warp(const float *L, const float *R, const float *prev, flo
 #define LWS_VW(CC)                                                                                                   \
     if (q16)                                                                                                          \
         hipLaunchKernelGGL((k_volume_l1_warp<CC, true>), grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m,  \
-                           mul_a, mul_b, plow, ph, pw, pmat, force_gather, plow0, ph0, pw0, pmat0);                       \
+                           mul_a, mul_b, plow, ph, pw, pmat, force_gather, plow0, ph0, pw0, pmat0, ioff);                 \
     else                                                                                                              \
         hipLaunchKernelGGL((k_volume_l1_warp<CC, false>), grid, block, 0, st, L, R, prev, cost, wflow_out, h, w, H, W, m, \
-                           mul_a, mul_b, plow, ph, pw, pmat, force_gather, plow0, ph0, pw0, pmat0)
+                           mul_a, mul_b, plow, ph, pw, pmat, force_gather, plow0, ph0, pw0, pmat0, ioff)
     switch (C) {
         case 8: LWS_VW(8); break;
         case 16: LWS_VW(16); break;

@@ -102,7 +102,7 @@ def main(argv=None):
         log.info("Successful load model")
     model.eval()
     if getattr(args, "split_bf16", False):
-        model.set_option("split_bf16", 1)
+        model.set_option("split_bf16", 7)
         log.info("split-bf16 numerics mode")
     if not args.left_img:                                               # :50-63
         if os.path.isdir(args.img_path):

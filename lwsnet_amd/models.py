@@ -93,8 +93,13 @@ class LWSNet:
             if torch.cuda.is_available() else None
         lib = _lib.load()                                         # raises if the HIP extension is missing
         self.feature_fp16 = bool(getattr(args, "feature_fp16", False))     # BASELINE config 5 (not in the reference)
+        # which source index the reference's four F.interpolate calls use (models.py:119,146,154,161): 0 = half-pixel centres
+        # (this build's reading of Paddle 2.0rc0), 1 = src = ratio * dst; not in the reference's namespace
+        self.interp_align_mode = int(getattr(args, "interp_align_mode", 0))
+        if self.interp_align_mode not in (0, 1):
+            raise ValueError(f"interp_align_mode must be 0 or 1, got {self.interp_align_mode}")
         cfg = _lib.LwsConfig((ctypes.c_int32 * 3)(*self.maxdisplist), self.layers_3d, self.channels_3d,
-                             (ctypes.c_int32 * 3)(*self.growth_rate), 1 if self.feature_fp16 else 0)
+                             (ctypes.c_int32 * 3)(*self.growth_rate), 1 if self.feature_fp16 else 0, self.interp_align_mode)
         self._h = ctypes.c_void_p()
         with self._device_ctx():
             _lib.check(lib.lws_create(ctypes.byref(cfg), ctypes.byref(self._h)), "lws_create")

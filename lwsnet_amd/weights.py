@@ -24,10 +24,13 @@ import numpy as np
 BN_SUFFIXES = ("weight", "bias", "_mean", "_variance")
 
 
-def default_args(maxdisplist=(24, 5, 5), layers_3d=4, channels_3d=8, growth_rate=(4, 1, 1), feature_fp16=False):
-    """The namespace the reference CLI builds (inference.py:23-26); feature_fp16 is this build's BASELINE-config-5 switch."""
+def default_args(maxdisplist=(24, 5, 5), layers_3d=4, channels_3d=8, growth_rate=(4, 1, 1), feature_fp16=False,
+                 interp_align_mode=0):
+    """The namespace the reference CLI builds (inference.py:23-26); feature_fp16 is this build's BASELINE-config-5 switch,
+    interp_align_mode its reading of Paddle's F.interpolate default (include/lwsnet_hip.h, lws_config)."""
     return SimpleNamespace(maxdisplist=list(maxdisplist), layers_3d=int(layers_3d),
-                           channels_3d=int(channels_3d), growth_rate=list(growth_rate), feature_fp16=bool(feature_fp16))
+                           channels_3d=int(channels_3d), growth_rate=list(growth_rate), feature_fp16=bool(feature_fp16),
+                           interp_align_mode=int(interp_align_mode))
 
 
 def _bn(spec, prefix, c):

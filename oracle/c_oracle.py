@@ -76,7 +76,17 @@ def volume_l1_shift(L, R, D):
     return cost
 
 
+def _sync_align_mode():
+    """The C restatement's resizes follow the SAME switch as the literal restatement's: oracle.lws_oracle.VARIANT["align_mode"]
+    (0 = half-pixel centres, the default every golden fixture was made with; 1 = src = ratio * dst)."""
+    from . import lws_oracle
+    mode = int(lws_oracle.VARIANT["align_mode"])
+    lib().lwso_set_align_mode(mode)
+    return mode
+
+
 def resize_bilinear(x, hout, wout, mul_a=1.0, mul_b=1.0):
+    _sync_align_mode()
     x = _c(x)
     lead = x.shape[:-2]
     hin, win = x.shape[-2:]
@@ -119,6 +129,7 @@ def softargmin(cost, start):
 
 
 def upsample_add(low, prev, H, W):
+    _sync_align_mode()
     low = _c(low)
     B, h, w = low.shape
     prev = _c(prev) if prev is not None else None

@@ -13,7 +13,7 @@
  *
  * Reference lines followed (all under /root/reference/models/):
  *   lwso_volume_l1_shift   models.py:58-76
- *   lwso_resize_bilinear   models.py:119-121 (F.interpolate, half-pixel) + the two scalar scales
+ *   lwso_resize_bilinear   models.py:119-121 (F.interpolate; align_mode: lwso_set_align_mode) + the two scalar scales
  *   lwso_volume_l1_warp    models.py:78-104 + warp :28-55 (grid_sample, align_corners=True, zeros)
  *   lwso_bnrelu_conv3d     submodules.py:190-204 (BatchNorm3D -> ReLU -> Conv3D k3 s1 p1, no bias)
  *   lwso_softargmin        models.py:142,151-152,167-179
@@ -80,10 +80,20 @@ LWSO_API void lwso_volume_l1_shift(const float *L, const float *R, float *cost,
                 }
 }
 
-/* Half-pixel bilinear source index (align_corners=False, align_mode=0). */
+/* Which source index F.interpolate(mode="bilinear", align_corners=False) uses (models.py:119,146,154,161) is a reading of
+ * Paddle 2.0rc0's defaults that cannot be checked offline, so it is a switch here exactly as it is
+ * in the product (lws_config.interp_align_mode) and in oracle/lws_oracle.py (VARIANT["align_mode"], which c_oracle.py
+ * forwards before every resize):  0 = half-pixel centres, src = ratio * (dst + 0.5) - 0.5;  1 = src = ratio * dst
+ * (Paddle's bilinear_interp with align_mode = 1: y_n = int(ratio * k), d_n = ratio * k - y_n).  One expression serves
+ * both: with off = 0 the additions are exact. */
+static float lwso_align_off = 0.5f;
+LWSO_API void lwso_set_align_mode(int mode) { lwso_align_off = mode == 1 ? 0.0f : 0.5f; }
+LWSO_API int lwso_get_align_mode(void) { return lwso_align_off == 0.0f ? 1 : 0; }
+
 static inline void lwso_src(int dst, float ratio, int in, int *i0, int *i1, float *l0, float *l1)
 {
-    float s = ratio * ((float)dst + 0.5f) - 0.5f;
+    const float off = lwso_align_off;
+    float s = ratio * ((float)dst + off) - off;
     if (s < 0.0f) s = 0.0f;
     int a = (int)s;
     if (a > in - 1) a = in - 1;

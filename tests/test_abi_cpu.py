@@ -26,13 +26,13 @@ def test_header_and_prototypes_agree():
 def test_library_exports_every_symbol(hip_lib):
     for name in _declared():
         assert hasattr(hip_lib, name), name
-    assert hip_lib.lws_abi_version() == 7
+    assert hip_lib.lws_abi_version() == 8
 
 
 def _create(lib, **kw):
     a = default_args(**kw)
     cfg = _lib.LwsConfig((ctypes.c_int32 * 3)(*a.maxdisplist), a.layers_3d, a.channels_3d,
-                         (ctypes.c_int32 * 3)(*a.growth_rate), 0)
+                         (ctypes.c_int32 * 3)(*a.growth_rate), 0, a.interp_align_mode)
     h = ctypes.c_void_p()
     rc = lib.lws_create(ctypes.byref(cfg), ctypes.byref(h))
     return rc, h
@@ -45,6 +45,11 @@ def test_create_rejects_unsupported_config(hip_lib):
         _lib.check(rc)
     rc, _ = _create(hip_lib, maxdisplist=(100, 5, 5))
     assert rc == _lib.LWS_ERR_INVALID
+    rc, _ = _create(hip_lib, interp_align_mode=2)          # lws_config.interp_align_mode (ABI v8): 0 or 1
+    assert rc == _lib.LWS_ERR_INVALID and b"interp_align_mode" in hip_lib.lws_last_error()
+    rc, h = _create(hip_lib, interp_align_mode=1)
+    assert rc == 0
+    hip_lib.lws_destroy(h)
 
 
 def test_set_tensor_validates_keys_and_shapes(hip_lib):
@@ -102,23 +107,25 @@ def test_options_validate_names_and_ranges(hip_lib):
     rc, h = _create(hip_lib)
     assert rc == 0
     v = ctypes.c_int(123)
-    for name, default in [(b"left_at", -1), (b"split_heads", -1), (b"fuse_shift", 1), (b"fuse_first", 1), (b"defer_upsample", 1), (b"mid8_form", 1), (b"side_streams", 1), (b"conv3d_order", 1), (b"ref_chunk_mb", 72), (b"ref_pipe", -1), (b"warp_form", 1), (b"mid8_balance", 1), (b"fuse_last1", 1), (b"mid8_tile", 0), (b"fork_ext", 1), (b"fork2_after", -1), (b"tail_at", -1), (b"fuse_ref_last", -1), (b"mid16_form", 0), (b"conv64_form", 0)]:
+    for name, default in [(b"fuse_first", 3), (b"defer_upsample", 1), (b"side_streams", 1), (b"split_bf16", 0), (b"ref_chunk_mb", 72),
+                          (b"ref_pipe", -1), (b"warp_form", 1), (b"fuse_last1", 1), (b"fork2_after", -1), (b"fuse_ref_last", -1)]:
         assert hip_lib.lws_get_option(h, name, ctypes.byref(v)) == 0 and v.value == default
-    assert hip_lib.lws_set_option(h, b"left_at", 2) == 0
-    assert hip_lib.lws_get_option(h, b"left_at", ctypes.byref(v)) == 0 and v.value == 2
-    assert hip_lib.lws_set_option(h, b"left_at", 1) == _lib.LWS_ERR_INVALID
-    assert hip_lib.lws_set_option(h, b"fuse_shift", 2) == _lib.LWS_ERR_INVALID
+    assert hip_lib.lws_set_option(h, b"fork2_after", 2) == 0
+    assert hip_lib.lws_get_option(h, b"fork2_after", ctypes.byref(v)) == 0 and v.value == 2
+    assert hip_lib.lws_set_option(h, b"fork2_after", 17) == _lib.LWS_ERR_INVALID
+    assert hip_lib.lws_set_option(h, b"fuse_first", 4) == _lib.LWS_ERR_INVALID
+    assert hip_lib.lws_set_option(h, b"warp_form", 2) == _lib.LWS_ERR_INVALID
     assert hip_lib.lws_set_option(h, b"bogus", 1) == _lib.LWS_ERR_INVALID
     assert b"unknown option" in hip_lib.lws_last_error()
-    # the opt-in numerics mode as one switch (the three options that change bits)
-    assert hip_lib.lws_get_option(h, b"split_bf16", ctypes.byref(v)) == 0 and v.value == 0
-    assert hip_lib.lws_set_option(h, b"split_bf16", 1) == 0
-    for name, want in [(b"mid16_form", 1), (b"conv64_form", 1), (b"mid8_form", 2), (b"split_bf16", 1)]:
-        assert hip_lib.lws_get_option(h, name, ctypes.byref(v)) == 0 and v.value == want
-    assert hip_lib.lws_set_option(h, b"split_bf16", 0) == 0
-    for name, want in [(b"mid16_form", 0), (b"conv64_form", 0), (b"mid8_form", 1), (b"split_bf16", 0)]:
-        assert hip_lib.lws_get_option(h, name, ctypes.byref(v)) == 0 and v.value == want
-    assert hip_lib.lws_set_option(h, b"mid8_form", 3) == _lib.LWS_ERR_INVALID
+    # ABI v8 retired the options two rounds of sweeps had shown to tie or lose, and the per-kernel forms of the numerics mode
+    for name in (b"left_at", b"split_heads", b"fuse_shift", b"conv3d_order", b"mid8_tile", b"mid8_balance", b"fork_ext", b"tail_at",
+                 b"mid8_form", b"mid16_form", b"conv64_form"):
+        assert hip_lib.lws_set_option(h, name, 0) == _lib.LWS_ERR_INVALID and hip_lib.lws_get_option(h, name, ctypes.byref(v)) == _lib.LWS_ERR_INVALID
+    # the opt-in numerics mode: a bit per MFMA convolution that has a split-bf16 form
+    for mask in (1, 2, 4, 7, 0):
+        assert hip_lib.lws_set_option(h, b"split_bf16", mask) == 0
+        assert hip_lib.lws_get_option(h, b"split_bf16", ctypes.byref(v)) == 0 and v.value == mask
+    assert hip_lib.lws_set_option(h, b"split_bf16", 8) == _lib.LWS_ERR_INVALID
     hip_lib.lws_destroy(h)
 
 

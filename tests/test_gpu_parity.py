@@ -117,20 +117,14 @@ def test_conv3d_stack_bitexact(dev, model, stage, shape):
     from oracle import c_oracle as C
     c = (np.random.default_rng(stage + 1).random(shape) * 12.0).astype(np.float32)
     want = C.conv3d_stack(c, model.state_dict(), stage)
-    for form in ((0, 1) if stage > 0 else (0,)):        # 8 -> 8 layers: 16x16x4 parity-row tiles and the 4x4x1_16B form
-        model.set_option("mid8_form", form)
-        try:
-            got = ops.conv3d_stack(model._h, stage, cu(c, dev))
-        finally:
-            model.set_option("mid8_form", 1)
-        assert_bits(got, want, f"conv3d_stack stage {stage} {shape} mid8_form={form}")
+    assert_bits(ops.conv3d_stack(model._h, stage, cu(c, dev)), want, f"conv3d_stack stage {stage} {shape}")
 
 
 @pytest.mark.parametrize("stage", [0, 1, 2])
 def test_conv3d_stack_ragged_sweep(dev, model, stage):
     """Seeded random volume shapes -- every extent down to 1, extents that are not multiples of any tile edge (3 x 4 x 16,
     3 x 4 x 32, 3 x 8 x 32 voxels; the 32-wide parity rows of the 8 -> 8 kernels), tiles that are all halo -- through
-    lws_conv3d_stack against the C oracle, bit for bit, in every exact kernel form (the tile choice follows the grid size)."""
+    lws_conv3d_stack against the C oracle, bit for bit (the tile choice follows the grid size)."""
     from lwsnet_amd import ops
     from oracle import c_oracle as C
     rng = np.random.default_rng(100 + stage)
@@ -140,13 +134,7 @@ def test_conv3d_stack_ragged_sweep(dev, model, stage):
     for shape in shapes:
         c = (rng.random(shape) * 12.0).astype(np.float32)
         want = C.conv3d_stack(c, model.state_dict(), stage)
-        for form in ((0, 1) if stage > 0 else (0,)):
-            model.set_option("mid8_form", form)
-            try:
-                got = ops.conv3d_stack(model._h, stage, cu(c, dev))
-            finally:
-                model.set_option("mid8_form", 1)
-            assert_bits(got, want, f"conv3d_stack stage {stage} {shape} mid8_form={form}")
+        assert_bits(ops.conv3d_stack(model._h, stage, cu(c, dev)), want, f"conv3d_stack stage {stage} {shape}")
 
 
 @pytest.mark.parametrize("stage", [0, 1])
@@ -362,23 +350,19 @@ def test_forward_repeatable_batch8(dev, model):
             assert torch.equal(one[s], ref[s][3:4])
 
 
-OPTION_PLANS = [{"left_at": 0}, {"left_at": 2}, {"split_heads": 1}, {"split_heads": 0}, {"fuse_shift": 0},
-                {"fuse_first": 0}, {"defer_upsample": 0}, {"mid8_form": 1}, {"mid8_form": 0},
-                {"conv3d_order": 1}, {"conv3d_order": 0}, {"ref_chunk_mb": 0}, {"ref_chunk_mb": 1},
-                {"side_streams": 0}, {"side_streams": 0, "left_at": 0}, {"left_at": 2, "split_heads": 1},
-                {"warp_form": 0}, {"warp_form": 0, "defer_upsample": 0}, {"mid8_balance": 0},
-                {"fuse_last1": 0}, {"fuse_last1": 1, "warp_form": 0},
-                {"fuse_ref_last": 0}, {"fuse_ref_last": 1}, {"mid8_tile": 2}, {"mid8_tile": 3}, {"mid8_tile": 4 + 8 * 1},
-                {"fork_ext": 0}, {"fork2_after": 0}, {"fork2_after": 2, "fork_ext": 0}, {"fork2_after": 1}, {"tail_at": 1}, {"tail_at": 2}, {"tail_at": 2, "fork2_after": 0, "fork_ext": 0}, {"tail_at": 0, "fork_ext": 0, "left_at": 0}, {"tail_at": 1, "split_heads": 1},
-                {"left_at": 0, "split_heads": 1, "fuse_shift": 0, "fuse_first": 0, "defer_upsample": 0, "mid8_form": 1}]
+OPTION_PLANS = [{"fuse_first": 0}, {"fuse_first": 1}, {"fuse_first": 2}, {"defer_upsample": 0}, {"ref_chunk_mb": 0}, {"ref_chunk_mb": 1},
+                {"side_streams": 0}, {"side_streams": 0, "fuse_first": 0}, {"warp_form": 0}, {"warp_form": 0, "defer_upsample": 0},
+                {"fuse_last1": 0}, {"fuse_last1": 1, "warp_form": 0}, {"fuse_ref_last": 0}, {"fuse_ref_last": 1},
+                {"fork2_after": 0}, {"fork2_after": 2}, {"fork2_after": 1, "side_streams": 0}, {"ref_pipe": 1, "ref_chunk_mb": 1},
+                {"ref_pipe": 0, "ref_chunk_mb": 1},
+                {"fuse_first": 0, "defer_upsample": 0, "fuse_last1": 0, "fuse_ref_last": 0, "fork2_after": 0, "warp_form": 0}]
 
 
 @pytest.mark.parametrize("plan", OPTION_PLANS, ids=lambda p: ",".join(f"{k}={v}" for k, v in p.items()))
 def test_forward_schedule_options(dev, hip_lib, plan):
     """lws_set_option (include/lwsnet_hip.h) only moves work between launches / streams: for every plan the four stage
-    maps equal the C oracle bit for bit at batch 1, and the batch-1 / batch-3 / batch-5 results agree pair by pair
-    (batch 5 with left_at=2 + split_heads=1 is the combination ADVICE r1 flagged: side2 must be ordered behind the
-    previous forward even when refinement1_left does not fork at the start)."""
+    maps equal the C oracle bit for bit at batch 1, and the batch-1 / batch-3 / batch-5 results agree pair by pair, six
+    forwards back to back (the side stream of call n+1 meets call n's readers)."""
     from lwsnet_amd.models import LWSNet
     from oracle import c_oracle as C
     m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
@@ -402,7 +386,95 @@ def test_forward_schedule_options(dev, hip_lib, plan):
     with pytest.raises(ValueError):
         m.set_option("no_such_option", 1)
     with pytest.raises(ValueError):
-        m.set_option("left_at", 1)
+        m.set_option("fuse_first", 4)
+    with pytest.raises(ValueError):
+        m.set_option("left_at", 2)                # (retired with ABI v8)
+
+
+def test_graph_capture_replays_the_forward(dev, hip_lib):
+    """include/lwsnet_hip.h promises hipGraph capture after lws_reserve (tools/graph_pipeline.py uses it).  Under capture the
+    forks of lws_forward must be capture-time records (hipEventRecord on the capturing stream): an event bound to a kernel's
+    completion signal does not pull the side stream into the graph.  Captured once, replayed on new inputs: the
+    four stage maps equal the eager forward bit for bit, at batch 1 (deferred maps, fused tails) and batch 3."""
+    from lwsnet_amd import _lib
+    from lwsnet_amd.models import LWSNet
+    m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
+    for B in (1, 3):
+        left, right = make_batch(2 * B, 64, 256, 900 + B)
+        lt, rt = cu(left[:B], dev), cu(right[:B], dev)
+        want_a = [p.clone() for p in m(lt, rt)]
+        want_b = [p.clone() for p in m(cu(left[B:], dev), cu(right[B:], dev))]
+        _lib.check(_lib.load().lws_reserve(m._h, B, 64, 256), "lws_reserve")
+        outs = [torch.empty((B, 1, 64, 256), device=dev) for _ in range(4)]
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            m(lt, rt, out=outs)
+        for o in outs:
+            o.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for s_ in range(4):
+            assert torch.equal(outs[s_], want_a[s_]), f"B={B} replay stage {s_ + 1}"
+        lt.copy_(cu(left[B:], dev))
+        rt.copy_(cu(right[B:], dev))
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        for s_ in range(4):
+            assert torch.equal(outs[s_], want_b[s_]), f"B={B} replay on new inputs, stage {s_ + 1}"
+        # and the eager path is undisturbed afterwards (no stale stop event, no leftover capture state)
+        again = m(lt, rt)
+        assert all(torch.equal(a, b) for a, b in zip(again, want_b))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("B,H,W,maxdisp0", [(1, 64, 256, 24), (3, 64, 256, 24), (1, 63, 255, 24), (2, 40, 264, 24), (1, 256, 512, 24)])
+def test_interp_align_mode_bitexact_vs_c_oracle(dev, hip_lib, mode, B, H, W, maxdisp0):
+    """lws_config.interp_align_mode: which source index the reference's four F.interpolate calls use
+    (/root/reference/models/models.py:119,146,154,161) is the one material bet of the oracle -- Paddle cannot be run here -- so
+    it is a switch in the product, in the C oracle (lwso_set_align_mode) and in the literal oracle (VARIANT["align_mode"]).
+    Under BOTH values the whole forward equals the C oracle bit for bit: batch 1 (deferred maps and fused last layers: every
+    consumer evaluates the resize itself), batch 3 (k_upsample_add / k_softargmin_upsample launches), odd sizes (non-integer
+    ratios) and the full 256x512 of BASELINE config 2; and the two modes really differ."""
+    from lwsnet_amd.models import LWSNet
+    from oracle import c_oracle as C, lws_oracle as O
+    sd = make_state_dict(7)
+    m = LWSNet(default_args(maxdisplist=(maxdisp0, 5, 5), interp_align_mode=mode), device=dev).set_state_dict(sd).eval()
+    left, right = make_batch(B, H, W, 700 + H)
+    got = m(left, right)
+    with O.variant(align_mode=mode):
+        want = C.forward(left, right, sd, (maxdisp0, 5, 5))
+    for s_ in range(4):
+        assert_bits(got[s_], want[s_], f"align_mode {mode} B={B} {H}x{W} stage {s_ + 1}")
+    with O.variant(align_mode=1 - mode):
+        other = C.forward(left[:1], right[:1], sd, (maxdisp0, 5, 5))
+    assert float(np.abs(other[3] - want[3][:1]).max()) > 0.05           # (sub-pixel shifts of every stage: tenths of a pixel)
+    for opts in ({"defer_upsample": 0}, {"fuse_last1": 0}, {"fuse_first": 0, "warp_form": 0}):
+        for k, v in opts.items():
+            m.set_option(k, v)
+        got2 = m(left, right)
+        for s_ in range(4):
+            assert_bits(got2[s_], want[s_], f"align_mode {mode} {opts} stage {s_ + 1}")
+
+
+def test_interp_align_mode_matches_the_literal_oracle(dev, hip_lib):
+    """The same switch against the LITERAL restatement (torch-CPU ops, oracle/lws_oracle.py with variant(align_mode=1)): the
+    HIP forward built with interp_align_mode = 1 sits on the float32 noise floor of that reading, and far from the other."""
+    from lwsnet_amd.models import LWSNet
+    from oracle import lws_oracle as O
+    sd = make_state_dict(7)
+    left, right = make_batch(1, 64, 256, 3)
+    m1 = LWSNet(default_args(interp_align_mode=1), device=dev).set_state_dict(sd).eval()
+    got = [p.cpu() for p in m1(left, right)]
+    with O.variant(align_mode=1):
+        lit1 = O.forward(left, right, sd)
+    lit0 = O.forward(left, right, sd)
+    for s_ in range(4):
+        assert float((got[s_] - lit1[s_]).abs().max()) < 2e-2, s_
+    assert float((got[3] - lit0[3]).abs().max()) > 0.05
+    with pytest.raises(ValueError):
+        LWSNet(default_args(interp_align_mode=2), device=dev)
 
 
 def test_handles_on_their_own_threads_and_streams(dev, hip_lib):
@@ -656,9 +728,9 @@ def test_forward_within_reference_source_noise_floor(dev, hip_lib, name, factor)
 
 
 def test_split_bf16_forward_on_the_float32_noise_floor(dev, hip_lib):
-    """The opt-in numerics mode: mid16_form = 1 (k_conv3d_mid16x, the stage-1 32 -> 32 Conv3D layers), mid8_form = 2
-    (k_conv3d_mid8x, the 8 -> 8 layers of stages 2 and 3) and conv64_form = 1 (k_ref_conv64x, refinement2[0]) on split-bf16 MFMA -- three bf16 values per float32 operand, six exact cross products
-    accumulated in float32.  NOT bit-exact against the oracle chain; never the default or the benchmark headline.
+    """The opt-in numerics mode, option "split_bf16" (a bit mask): 1 = k_conv3d_mid16x, the stage-1 32 -> 32 Conv3D layers, 2 =
+    k_conv3d_mid8x, the 8 -> 8 layers of stages 2 and 3, 4 = k_ref_conv64x, refinement2[0], on split-bf16 MFMA -- three bf16
+    values per float32 operand, six exact cross products accumulated in float32.  NOT bit-exact against the oracle chain; never the default or the benchmark headline.
     VERDICT r2 item 8's condition -- no further from float64 than the float32 chain is -- cannot be a single-sample
     comparison (two float32 builds of this chaotic pipeline differ from each other by as much as either differs from
     float64), so it is asserted on aggregates over six pairs (five seeded smooth pairs and the white-noise pair) against
@@ -671,7 +743,7 @@ def test_split_bf16_forward_on_the_float32_noise_floor(dev, hip_lib):
     sd = make_state_dict(7)
     m = LWSNet(default_args(), device=dev).set_state_dict(sd).eval()
     H, W, npairs = 128, 384, 6                    # (stage 3 = 9 x 64 x 192: enough tiles for k_conv3d_mid8x to be selected)
-    modes = {"exact": (0, 0, 1), "mid16x": (1, 0, 1), "conv64x": (0, 1, 1), "mid8x": (0, 0, 2), "all": (1, 1, 2)}
+    modes = {"exact": 0, "mid16x": 1, "conv64x": 4, "mid8x": 2, "all": 7}
     agg = {k: {"max": np.zeros(4), "mean": np.zeros(4)} for k in modes}
     differs = {k: False for k in modes}
     try:
@@ -680,10 +752,8 @@ def test_split_bf16_forward_on_the_float32_noise_floor(dev, hip_lib):
             l, r = l[None], r[None]
             ref64 = lws_oracle.forward(l, r, sd, (24, 5, 5), dtype=torch.float64)
             res = {}
-            for name, (f16, f64, f8) in modes.items():
-                m.set_option("mid16_form", f16)
-                m.set_option("conv64_form", f64)
-                m.set_option("mid8_form", f8)
+            for name, mask in modes.items():
+                m.set_option("split_bf16", mask)
                 res[name] = [p.clone() for p in m(l, r)]
                 differs[name] = differs[name] or any(not torch.equal(a, b) for a, b in zip(res["exact"], res[name]))
                 for s in range(4):
@@ -694,9 +764,7 @@ def test_split_bf16_forward_on_the_float32_noise_floor(dev, hip_lib):
                 assert torch.equal(res["conv64x"][s], res["exact"][s])
             assert torch.equal(res["mid8x"][0], res["exact"][0])         # stage 1 has no 8 -> 8 layer
     finally:
-        m.set_option("mid16_form", 0)
-        m.set_option("conv64_form", 0)
-        m.set_option("mid8_form", 1)
+        m.set_option("split_bf16", 0)
     for name in modes:
         print(f"{name:8s} mean |. - fp64| per stage", agg[name]["mean"], " max", agg[name]["max"])
     for name in ("mid16x", "conv64x", "mid8x", "all"):
@@ -708,7 +776,7 @@ def test_split_bf16_forward_on_the_float32_noise_floor(dev, hip_lib):
 
 @pytest.mark.parametrize("B,H,W", [(1, 64, 256), (2, 40, 72), (1, 63, 255), (1, 136, 152)])
 def test_split_bf16_refine_close_to_the_exact_chain(dev, model, B, H, W):
-    """lws_refine with conv64_form = 1 (k_ref_conv64x) against the C oracle's exact chain: the refined map moves by
+    """lws_refine with split_bf16 = 4 (k_ref_conv64x) against the C oracle's exact chain: the refined map moves by
     float32 rounding noise only (a 576-term contraction, then four depthwise-separable blocks and the last convolution),
     including ragged tiles and image borders of the dilation-8 phase grid; the exact form comes back bit for bit."""
     from lwsnet_amd import ops
@@ -717,11 +785,11 @@ def test_split_bf16_refine_close_to_the_exact_chain(dev, model, B, H, W):
     left = rng.standard_normal((B, 3, H, W)).astype(np.float32)
     pred3 = (rng.random((B, 1, H, W)) * 150.0).astype(np.float32)
     want = C.refine(left, pred3, model.state_dict())
-    model.set_option("conv64_form", 1)
+    model.set_option("split_bf16", 4)
     try:
         got = ops.refine(model._h, cu(left, dev), cu(pred3, dev)).cpu().numpy()
     finally:
-        model.set_option("conv64_form", 0)
+        model.set_option("split_bf16", 0)
     resid = float(np.abs(want - pred3).max())                            # size of the refinement's own contribution
     err = float(np.abs(got - want).max())
     print(f"split-bf16 refine {B}x{H}x{W}: max |diff| {err:.3e}, refinement residual scale {resid:.3f}")
@@ -730,9 +798,9 @@ def test_split_bf16_refine_close_to_the_exact_chain(dev, model, B, H, W):
 
 
 @pytest.mark.parametrize("stage,option,value,shapes", [
-    (0, "mid16_form", 1, [(1, 24, 32, 64), (2, 23, 10, 40)]),
-    (1, "mid8_form", 2, [(2, 9, 96, 160), (1, 7, 93, 170)]),         # (PER-SAMPLE grids under 256 tiles stay on the exact kernel)
-    (2, "mid8_form", 2, [(1, 9, 128, 256), (2, 9, 69, 191)])])
+    (0, "split_bf16", 1, [(1, 24, 32, 64), (2, 23, 10, 40)]),
+    (1, "split_bf16", 2, [(2, 9, 96, 160), (1, 7, 93, 170)]),        # (PER-SAMPLE grids under 256 tiles stay on the exact kernel)
+    (2, "split_bf16", 2, [(1, 9, 128, 256), (2, 9, 69, 191)])])
 def test_split_bf16_stack_close_to_the_exact_chain(dev, model, stage, option, value, shapes):
     """lws_conv3d_stack with the split-bf16 middle layers (stage 1: k_conv3d_mid16x, C3 = 32; stages 2-3: k_conv3d_mid8x,
     C3 = 8) against the C oracle's exact chain: float32-level agreement (six layers deep; tools/micro/split_bf16.hip measures
@@ -754,7 +822,7 @@ def test_split_bf16_stack_close_to_the_exact_chain(dev, model, stage, option, va
         print(f"split-bf16 stack stage {stage + 1} {shape}: max |diff| {err:.3e} at output scale {scale:.3f}")
         assert err <= 2e-5 * scale and err > 0.0
         assert_bits(ops.conv3d_stack(model._h, stage, cu(c, dev)), want, "exact form restored")
-    if option == "mid8_form":
+    if value == 2:
         # the kernel choice of this mode depends on the per-sample geometry only: a pair gets the same bits at
         # every batch size -- here a 3 x 9 x 27 = 81-tile sample stays on the exact kernel at batch 1 and at batch 8 alike
         c = (np.random.default_rng(6).random((8, 9, 33, 95)) * 12.0).astype(np.float32)
@@ -1097,7 +1165,7 @@ def test_profiler_counts_and_sampling(dev, model, hip_lib):
     _lib.check(hip_lib.lws_profile_read(model._h, tot, cnt))
     got = dict(zip(names, list(cnt)))
     assert got["conv3d_mid16"] == 4 and got["conv3d_mid8"] == 8 and got["conv3d_first"] == 3 and got["conv3d_last"] == 3
-    # (the stage-1 volume is built inside the first Conv3D launch unless lws_set_option("fuse_shift", 0))
+    # (the stage-1 volume is built inside the first Conv3D launch)
     # (batch 1: refinement2's last block runs inside k_ref_dws_last, class ref_last, unless lws_set_option("fuse_ref_last", 0);
     # stage 1's soft-argmin inside its last Conv3D layer, and no k_upsample_add launch, unless "fuse_last1" / "defer_upsample" = 0)
     assert got["volume_l1_shift"] in (0, 1) and got["volume_l1_warp"] == 2 and got["ref_conv64"] == 1 and got["ref_dws"] == 11

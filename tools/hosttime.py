@@ -56,7 +56,7 @@ for K in (1, 2, 4):
     ts.sort()
     print(f"B={B} lws_forward (C), {K} call(s) into an empty queue: host {ts[len(ts) // 2]:7.1f} us per call (median of 40; min {ts[0]:.1f})")
 # ... and where inside the call the host time goes: the same with the side-stream work switched off piecewise
-for opts, what in (({"left_at": 0}, "refinement1_left issued at the start"), ({"side_streams": 0}, "one stream, no events")):
+for opts, what in (({"side_streams": 0}, "one stream, no events"),):
     for k, v in opts.items():
         m.set_option(k, v)
     ts = []
@@ -68,4 +68,3 @@ for opts, what in (({"left_at": 0}, "refinement1_left issued at the start"), ({"
     ts.sort()
     print(f"B={B} lws_forward (C), 1 call into an empty queue, {what}: host {ts[len(ts) // 2]:7.1f} us (min {ts[0]:.1f})")
     m.set_option("side_streams", 1)
-    m.set_option("left_at", -1)

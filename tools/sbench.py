@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Conv3D stack of one stage alone (lws_conv3d_stack): per-kernel-class averages, 16x16x4 parity-row tiles (mid8_form 0) vs 4x4x1_16B (mid8_form 1) vs split-bf16 (mid8_form 2, not bit-exact) (dev aid)."""
+"""Conv3D stack of one stage alone (lws_conv3d_stack): per-kernel-class averages, k_conv3d_mid8q (4x4x1_16B, exact) vs k_conv3d_mid8x (option split_bf16 = 2, not bit-exact) (dev aid)."""
 import argparse, ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,8 +21,8 @@ for o in a.opt:
     m.set_option(o.split('=')[0], int(o.split('=')[1]))
 for stage, (D, div) in ((1, (9, 4)), (2, (9, 2))):
     c = torch.rand((a.batch, D, H // div, W // div), device=dev) * 12
-    for form in (0, 1, 2):
-        m.set_option("mid8_form", form)
+    for form in (0, 2):                      # option "split_bf16": 0 = k_conv3d_mid8q (exact), 2 = k_conv3d_mid8x (not bit-exact)
+        m.set_option("split_bf16", form)
         for _ in range(5):
             ops.conv3d_stack(m._h, stage, c)
         torch.cuda.synchronize()
@@ -37,4 +37,4 @@ for stage, (D, div) in ((1, (9, 4)), (2, (9, 2))):
         kc = 4
         avg = tot[kc] / cnt[kc] * 1e3
         gf = 2 * 27 * 8 * 8 * a.batch * D * (H // div) * (W // div)
-        print(f"stage {stage + 1} B={a.batch} {opts} mid8_form={form}: k_conv3d_mid8 avg {avg:7.2f} us = {gf / avg / 1e6:6.1f} TF useful")
+        print(f"stage {stage + 1} B={a.batch} {opts} split_bf16={form}: k_conv3d_mid8{'x' if form else 'q'} avg {avg:7.2f} us = {gf / avg / 1e6:6.1f} TF useful")

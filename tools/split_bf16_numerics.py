@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Numerics account of option split_bf16 = 1 (k_conv3d_mid16x / k_conv3d_mid8x / k_ref_conv64x: split-bf16 MFMA in the Conv3D
-middle layers and in refinement2[0]; --only mid16_form | mid8_form | conv64_form for one of them; k_conv3d_mid8x is only selected
+middle layers and in refinement2[0]; --only mid16 | mid8 | conv64 for one of them (bits 1 / 2 / 4 of option split_bf16); k_conv3d_mid8x is only selected
 for grids of >= 256 tiles, i.e. from about 128x384 up):
 per stage, max and mean |result - float64 literal oracle| of (a) the exact HIP build (the oracle's float32 chain bit for bit),
 (b) the split-bf16 build, (c) the float32 literal oracle, over several seeded pairs.  VERDICT r2 item 8: the split form is
@@ -13,7 +13,7 @@ import torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=6)
 ap.add_argument("--size", default="64x256")
-ap.add_argument("--only", default="", help="mid16_form, mid8_form or conv64_form: switch only this option (default: all three)")
+ap.add_argument("--only", default="", help="mid16, mid8 or conv64: switch only this kernel family (default: all three)")
 a = ap.parse_args()
 H, W = [int(v) for v in a.size.split("x")]
 from lwsnet_amd.models import LWSNet
@@ -28,9 +28,9 @@ torch.set_num_threads(16)
 
 def set_mode(on):
     if a.only:
-        m.set_option(a.only, {"mid8_form": (1, 2)}.get(a.only, (0, 1))[int(on)])
+        m.set_option("split_bf16", {"mid16": 1, "mid8": 2, "conv64": 4}[a.only] if on else 0)
     else:
-        m.set_option("split_bf16", int(on))
+        m.set_option("split_bf16", 7 if on else 0)
 
 
 acc = {k: {"max": np.zeros(4), "mean": np.zeros(4)} for k in ("exact HIP", "split-bf16 HIP", "float32 literal oracle")}

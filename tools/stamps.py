@@ -35,12 +35,8 @@ from lwsnet_amd.weights import default_args, make_state_dict
 dev = torch.device('cuda:0')
 m = LWSNet(default_args(), device=dev).set_state_dict(make_state_dict(7)).eval()
 lib = ctypes.CDLL(_lib.LIB_PATH)
-if kid == 18:
-    m.set_option("mid8_form", 1)
 if kid in (19, 20, 21):
-    m.set_option({19: "mid16_form", 20: "mid8_form", 21: "conv64_form"}[kid], 2 if kid == 20 else 1)
-if kid == 2:
-    m.set_option("mid8_form", 0)
+    m.set_option("split_bf16", {19: 1, 20: 2, 21: 4}[kid])
 if driver == "stack":
     shape = [(B, 24, 32, 64), (B, 9, 64, 128), (B, 9, 128, 256)][arg]
     c = torch.rand(shape, device=dev) * 12
