@@ -143,8 +143,10 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  * the opt-in numerics mode "split_bf16".  (ABI v8 removed the options two rounds of sweeps had retired: left_at, split_heads,
  * fuse_shift, conv3d_order, mid8_tile, mid8_balance, fork_ext, tail_at, and folded mid8_form / mid16_form / conv64_form into
  * "split_bf16"; what was measured against what is in profiles/NOTES.md.)
- *   "fuse_first"     bit mask, 3 (default): bit 0 = refinement1_disp's 1 -> 32 convolution, bit 1 = refinement1_left's 3 -> 32
- *                    convolution inside their first depthwise blocks (one launch and one 32-channel map less each)
+ *   "fuse_first"     bit mask, 1 (default): bit 0 = refinement1_disp's 1 -> 32 convolution, bit 1 = refinement1_left's 3 -> 32
+ *                    convolution inside their first depthwise blocks (one launch and one 32-channel map less each; bit 1
+ *                    measured neutral at every batch in round 6 -- the recomputed 27-tap convolution costs the block what the
+ *                    launch and the map cost the stream -- hence off by default)
  *   "defer_upsample" 1 (default) = at batches <= 2 the consumers evaluate the stage-2/3 maps
  *   "split_bf16"     0 (default) or a bit mask: 1 = the 32 -> 32 Conv3D layers (k_conv3d_mid16x), 2 = the 8 -> 8 Conv3D layers
  *                    of stages 2, 3 (k_conv3d_mid8x; samples under 256 tiles stay on the exact kernel), 4 = refinement2[0]
@@ -216,13 +218,15 @@ int lws_profile_read(lws_handle h, double *total_ms, int64_t *launches);
  * launches of k_conv3d_mid8 with it). */
 int lws_profile_read_class(lws_handle h, int kernel_class, float *ms_out, int capacity, int *count);
 const char *lws_kernel_class_name(int kernel_class);
-/* The clock the dominant kernel really runs at (ABI v8): launches the stage-1 32 -> 32 Conv3D layer (k_conv3d_mid16) of a
- * B x H x W forward eight times back to back on `stream` -- outside any timed region; its inputs are whatever the workspace
- * holds -- and in the last launch the first 64 workgroups stamp s_memtime (shader clock) and s_memrealtime (100 MHz) at
- * their first and last instruction.  *ghz = median over those workgroups of d s_memtime / d s_memrealtime x 100 MHz.
- * Synchronises `stream`.  bench.py reports it as roofline.clock_ghz (per rank for N > 1): a box that holds a lower clock
- * shows up here, not as an unexplained slower step.  LWS_ERR_STATE when stage 1's C3 is 8 (no k_conv3d_mid16 in the model). */
-int lws_clock_probe(lws_handle h, int B, int H, int W, void *stream, double *ghz);
+/* The clock the dominant kernel really runs at (ABI v8).  lws_clock_stamp(h, 1): from now on every k_conv3d_mid16 launch made
+ * through this handle (the four 32 -> 32 Conv3D layers of stage 1) has its first 64 workgroups leave s_memtime (shader clock)
+ * and s_memrealtime (100 MHz) of their first and last instruction in a handle-owned buffer (a scalar branch in the kernel,
+ * nothing when off); the latest launch wins.  lws_clock_read synchronises the device and returns the median over those
+ * workgroups of d s_memtime / d s_memrealtime x 100 MHz for the latest stamped launch.  bench.py stamps a few forwards right
+ * after its timed region -- same queue depth, same mix of kernels -- and reports roofline.clock_ghz (per rank for N > 1): a box
+ * or rank that holds a lower clock shows up there, not as an unexplained slower step.  LWS_ERR_STATE when stage 1's C3 is 8. */
+int lws_clock_stamp(lws_handle h, int enable);
+int lws_clock_read(lws_handle h, double *ghz);
 
 /* ---- several forwards in flight (no counterpart in the reference: inference.py:105-109 is one thread, one stream) ---- */
 /* A second handle for the same model on the same device: shares src's (read-only) parameter slab, owns its workspace,

@@ -49,7 +49,8 @@ PROTOTYPES = {
     "lws_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double), c_int64_p]),
     "lws_profile_read_class": (_i, [_vp, _i, c_float_p, _i, ctypes.POINTER(_i)]),
     "lws_kernel_class_name": (ctypes.c_char_p, [_i]),
-    "lws_clock_probe": (_i, [_vp, _i, _i, _i, _vp, ctypes.POINTER(ctypes.c_double)]),
+    "lws_clock_stamp": (_i, [_vp, _i]),
+    "lws_clock_read": (_i, [_vp, ctypes.POINTER(ctypes.c_double)]),
     "lws_clone": (_i, [_vp, ctypes.POINTER(_vp)]),
     "lws_pool_create": (_i, [_vp, _i, _i, ctypes.POINTER(_vp)]),
     "lws_pool_destroy": (_i, [_vp]),

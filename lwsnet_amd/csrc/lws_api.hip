@@ -810,6 +810,8 @@ static int stages_impl(lws_ctx *h, const float *const featsL[3], const float *co
 // handle's (recorded by lws_create, or set with lws_set_option("device")): its parameter slab, workspace, streams and
 // events live there, and a launch from another device would run on foreign pointers.  Checked, never switched: a C
 // library that silently changes the caller's current device is worse than one that refuses.
+static constexpr int kClockWgs = 64;      // workgroups of a stamped k_conv3d_mid16 launch that leave their clocks
+
 static int check_device(const lws_ctx *h, const char *what)
 {
     int cur = -1;
@@ -1013,44 +1015,40 @@ int lws_profile_read_class(lws_handle h, int kernel_class, float *ms_out, int ca
     return LWS_OK;
 }
 
-int lws_clock_probe(lws_handle h, int B, int H, int W, void *stream, double *ghz)
+int lws_clock_stamp(lws_handle h, int enable)
 {
-    LWS_CHECK_ARG(h && ghz, "lws_clock_probe: null argument");
-    int rc = check_size(h, B, H, W);
-    if (rc) return rc;
-    LWS_CHECK_DEVICE(h, "lws_clock_probe");
-    if (!h->finalized || h->stage[0].c3 == 8) {
-        set_error("lws_clock_probe: needs a finalized model whose stage-1 stack runs k_conv3d_mid16 (C3 = 16 or 32)");
+    LWS_CHECK_ARG(h, "lws_clock_stamp: null handle");
+    LWS_CHECK_DEVICE(h, "lws_clock_stamp");
+    if (enable) {
+        if (h->stage[0].c3 == 8) {
+            set_error("lws_clock_stamp: stage 1 of this model has C3 = 8: no k_conv3d_mid16 launch to stamp");
+            return LWS_ERR_STATE;
+        }
+        if (!h->clk_buf) LWS_HIP(hipMalloc(&h->clk_buf, kClockWgs * 4 * sizeof(unsigned long long)));
+        LWS_HIP(hipMemset(h->clk_buf, 0, kClockWgs * 4 * sizeof(unsigned long long)));
+    }
+    h->stage[0].clk = enable ? h->clk_buf : nullptr;
+    return LWS_OK;
+}
+
+int lws_clock_read(lws_handle h, double *ghz)
+{
+    LWS_CHECK_ARG(h && ghz, "lws_clock_read: null argument");
+    LWS_CHECK_DEVICE(h, "lws_clock_read");
+    if (!h->clk_buf) {
+        set_error("lws_clock_read: lws_clock_stamp(h, 1) was never called");
         return LWS_ERR_STATE;
     }
-    const WsLayout L = ws_layout(h, B, H, W);
-    rc = ensure_ws(h, L.total);
-    if (rc) return rc;
-    constexpr int kWg = 64, kRuns = 8;
-    if (!h->clk_buf) LWS_HIP(hipMalloc(&h->clk_buf, kWg * 4 * sizeof(unsigned long long)));
-    hipStream_t st = (hipStream_t)stream;
-    LWS_HIP(hipMemsetAsync(h->clk_buf, 0, kWg * 4 * sizeof(unsigned long long), st));
-    int D, hh, ww;
-    stage_dims(h, 0, H, W, D, hh, ww);
-    (void)stop_event_take();
-    // the stage-1 middle layer on whatever the workspace holds (the activations of the last forward, or anything finite
-    // enough: the timing does not depend on the values), back to back; the last launch carries the stamps
-    for (int i = 0; i < kRuns && rc == LWS_OK; ++i) {
-        h->stage[0].clk = i == kRuns - 1 ? h->clk_buf : nullptr;
-        rc = launch_conv3d_mid(h->stage[0], 1, h->ws + L.act_a, h->ws + L.act_b, B, D, hh, ww, st);
-    }
-    h->stage[0].clk = nullptr;
-    if (rc) return rc;
-    unsigned long long host[kWg * 4];
-    LWS_HIP(hipMemcpyAsync(host, h->clk_buf, sizeof(host), hipMemcpyDeviceToHost, st));
-    LWS_HIP(hipStreamSynchronize(st));
+    unsigned long long host[kClockWgs * 4];
+    LWS_HIP(hipDeviceSynchronize());
+    LWS_HIP(hipMemcpy(host, h->clk_buf, sizeof(host), hipMemcpyDeviceToHost));
     std::vector<double> v;
-    for (int i = 0; i < kWg; ++i) {
+    for (int i = 0; i < kClockWgs; ++i) {
         const unsigned long long c0 = host[4 * i], r0 = host[4 * i + 1], c1 = host[4 * i + 2], r1 = host[4 * i + 3];
         if (r1 > r0 && c1 > c0) v.push_back((double)(c1 - c0) / (double)(r1 - r0) * 0.1);      // shader cycles per 10 ns tick -> GHz
     }
     if (v.empty()) {
-        set_error("lws_clock_probe: no workgroup left a usable stamp");
+        set_error("lws_clock_read: no stamped k_conv3d_mid16 launch since lws_clock_stamp(h, 1)");
         return LWS_ERR_STATE;
     }
     std::sort(v.begin(), v.end());

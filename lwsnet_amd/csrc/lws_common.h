@@ -167,7 +167,7 @@ struct Stage3d {
     bool mid16_split = false;          // 32 -> 32 layers: false = k_conv3d_mid16 (f32 MFMA, the oracle's chain), true = k_conv3d_mid16x (split-bf16, not bit-exact)
     int mid8_balance = 1;              // k_conv3d_mid8q on small grids: the small tile whenever that is the fullest CU's shorter schedule (0 in lws_pool workers)
     int cu_count = 0;                  // compute units of the handle's device (0 = unknown: 256)
-    unsigned long long *clk = nullptr; // lws_clock_probe: k_conv3d_mid16 stamps its shader / wall clocks here (64 x 4 values)
+    unsigned long long *clk = nullptr; // lws_clock_stamp: k_conv3d_mid16 leaves its shader / wall clocks here (64 x 4 values)
     std::vector<Conv3dLayer> layers;   // layers_3d + 2
 };
 
@@ -217,7 +217,7 @@ struct lws_ctx {
     lws_config cfg;
     // schedule options (lws_set_option): every setting computes the same bits, only the launch plan differs
     struct {
-        int fuse_first = 3;        // bit 0: refinement1_disp's 1 -> 32, bit 1: refinement1_left's 3 -> 32 convolution inside their first depthwise blocks
+        int fuse_first = 1;        // bit 0: refinement1_disp's 1 -> 32, bit 1: refinement1_left's 3 -> 32 convolution inside their first depthwise blocks
         int defer_upsample = 1;    // batches <= 2: consumers evaluate the stage-2/3 maps (no k_upsample_add launches)
         int side_streams = 1;      // 0: no handle-owned side stream, the whole forward on the caller's stream (lws_pool workers)
         int split_bf16 = 0;        // bit mask of the MFMA convolutions on split-bf16 operands (NOT bit-exact): 1 = Conv3D 32 -> 32, 2 = Conv3D 8 -> 8, 4 = refinement2[0]
@@ -255,7 +255,7 @@ struct lws_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_feat[3] = {nullptr, nullptr, nullptr};   // f8 / f4 / f2 complete
     hipEvent_t ev_fork2 = nullptr;                          // second fork of lws_forward (beside the end of stage 1's Conv3D stack)
-    unsigned long long *clk_buf = nullptr;                  // lws_clock_probe's device buffer
+    unsigned long long *clk_buf = nullptr;                  // lws_clock_stamp's device buffer
 };
 
 namespace lws {

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * WR * WM) void k_conv3d_mid16(const float *__re
                                                               int tiles_x, int tiles_y, int wt, int tiles_d,
                                                               unsigned long long *__restrict__ clk)
 {
-    // clk != nullptr (lws_clock_probe only; kernel-uniform, so a scalar branch): the first 64 workgroups leave the shader-clock
+    // clk != nullptr (lws_clock_stamp only; kernel-uniform, so a scalar branch): the first 64 workgroups leave the shader-clock
     // counter (s_memtime) and the 100 MHz wall clock (s_memrealtime) of their first and last instruction -- the clock this
     // kernel really ran at is d s_memtime / d s_memrealtime x 100 MHz (bench.py: roofline.clock_ghz)
     unsigned long long clk_c0 = 0, clk_r0 = 0;

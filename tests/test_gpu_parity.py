@@ -350,7 +350,7 @@ def test_forward_repeatable_batch8(dev, model):
             assert torch.equal(one[s], ref[s][3:4])
 
 
-OPTION_PLANS = [{"fuse_first": 0}, {"fuse_first": 1}, {"fuse_first": 2}, {"defer_upsample": 0}, {"ref_chunk_mb": 0}, {"ref_chunk_mb": 1},
+OPTION_PLANS = [{"fuse_first": 0}, {"fuse_first": 3}, {"fuse_first": 2}, {"defer_upsample": 0}, {"ref_chunk_mb": 0}, {"ref_chunk_mb": 1},
                 {"side_streams": 0}, {"side_streams": 0, "fuse_first": 0}, {"warp_form": 0}, {"warp_form": 0, "defer_upsample": 0},
                 {"fuse_last1": 0}, {"fuse_last1": 1, "warp_form": 0}, {"fuse_ref_last": 0}, {"fuse_ref_last": 1},
                 {"fork2_after": 0}, {"fork2_after": 2}, {"fork2_after": 1, "side_streams": 0}, {"ref_pipe": 1, "ref_chunk_mb": 1},
@@ -1170,8 +1170,30 @@ def test_profiler_counts_and_sampling(dev, model, hip_lib):
     # stage 1's soft-argmin inside its last Conv3D layer, and no k_upsample_add launch, unless "fuse_last1" / "defer_upsample" = 0)
     assert got["volume_l1_shift"] in (0, 1) and got["volume_l1_warp"] == 2 and got["ref_conv64"] == 1 and got["ref_dws"] == 11
     assert got["ref_last"] == 1 and got["softargmin"] == 0 and got["upsample_add"] == 0 and got["feature_conv2d"] == 8
+    assert got["ref_first"] == 1
     assert sum(cnt) == 4 + 8 + 3 + 3 + 2 + 1 + 11 + 1 + 8 + 1        # 42 launches per batch-1 forward (33 on the caller's stream)
     assert all(t >= 0.0 for t in tot) and tot[names.index("conv3d_mid16")] > 0.0
+    # "fuse_first" bit 1: refinement1_left's 3 -> 32 convolution inside its first block -- one launch less, the same bits
+    want = [p.clone() for p in model(left, right)]
+    model.set_option("fuse_first", 3)
+    try:
+        _lib.check(hip_lib.lws_profile_enable(model._h, -1))
+        fused = model(left, right)
+        torch.cuda.synchronize()
+        _lib.check(hip_lib.lws_profile_read(model._h, tot, cnt))
+        assert cnt[names.index("ref_first")] == 0 and cnt[names.index("ref_dws")] == 11 and sum(cnt) == 41
+        assert all(torch.equal(a, b) for a, b in zip(fused, want))
+    finally:
+        model.set_option("fuse_first", 1)
+    # lws_clock_stamp / lws_clock_read: the shader clock k_conv3d_mid16 ran at, from its own s_memtime / s_memrealtime stamps
+    ghz = ctypes.c_double(0.0)
+    _lib.check(hip_lib.lws_clock_stamp(model._h, 1))
+    for _ in range(4):
+        stamped = model(left, right)
+    _lib.check(hip_lib.lws_clock_read(model._h, ctypes.byref(ghz)))
+    _lib.check(hip_lib.lws_clock_stamp(model._h, 0))
+    assert 0.5 < ghz.value < 3.0, ghz.value
+    assert all(torch.equal(a, b) for a, b in zip(stamped, want))          # stamping does not touch the result
     # sampling: 6 calls, every 3rd recorded -> 2 forwards' worth of mid16 launches
     _lib.check(hip_lib.lws_profile_enable(model._h, 1 << names.index("conv3d_mid16")))
     _lib.check(hip_lib.lws_profile_sample(model._h, 3))
@@ -1183,3 +1205,38 @@ def test_profiler_counts_and_sampling(dev, model, hip_lib):
     _lib.check(hip_lib.lws_profile_enable(model._h, 0))
     with pytest.raises(Exception):
         _lib.check(hip_lib.lws_profile_sample(model._h, 0))
+
+
+def test_cli_directory_pipeline_writes_identical_files(dev, hip_lib, tmp_path):
+    """`python -m lwsnet_amd.inference --img_path DIR --workers N`: the reference's directory loop
+    (/root/reference/inference.py:50-63,88-137) pipelined -- host threads decode into pinned buffers, a copy stream uploads,
+    lws_pool keeps forwards in flight, the stage-4 maps come back on a second copy stream, host threads colour-map and encode.
+    Twelve distinct pairs (the reference's KITTI pair, shifted) plus one image that is too small (skipped, inference.py:96-97):
+    the files are byte-identical to the sequential loop's, for two worker counts."""
+    from PIL import Image
+    from lwsnet_amd import inference as inf
+    kp = os.path.join(ROOT, "tests", "golden", "kitti_pair")
+    l0 = np.asarray(Image.open(os.path.join(kp, "left_test.png")).convert("RGB"))
+    r0 = np.asarray(Image.open(os.path.join(kp, "right_test.png")).convert("RGB"))
+    src = tmp_path / "kitti"
+    for d in ("image_2", "image_3"):
+        (src / d).mkdir(parents=True)
+    for i in range(12):
+        Image.fromarray(np.roll(l0, 7 * i, axis=1)).save(src / "image_2" / f"{i:06d}_10.png")
+        Image.fromarray(np.roll(r0, 7 * i, axis=1)).save(src / "image_3" / f"{i:06d}_10.png")
+    Image.fromarray(l0[:300]).save(src / "image_2" / "000099_10.png")          # 300 rows < 368: skipped
+    Image.fromarray(r0[:300]).save(src / "image_3" / "000099_10.png")
+
+    def run(tag, *extra):
+        out = tmp_path / tag
+        written = inf.main(["--img_path", str(src), "--save_path", str(out), "--synthetic_weights", *extra])
+        assert len(written) == 12 and sorted(os.listdir(out)) == sorted(os.path.basename(w) for w in written)
+        return {n: (out / n).read_bytes() for n in sorted(os.listdir(out))}
+
+    seq = run("seq")
+    assert len(set(seq.values())) == 12                                         # twelve different maps
+    for w, g in ((1, 1), (4, 3)):
+        got = run(f"w{w}", "--workers", str(w), "--gpu_workers", str(g))
+        assert got == seq, f"--workers {w}: files differ from the sequential loop"
+        st = inf.main.last_stats
+        assert st["pairs"] == 12 and st["skipped"] == 1 and st["pairs_per_s"] > 0

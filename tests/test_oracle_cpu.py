@@ -232,3 +232,24 @@ def test_oracle_variant_switches(state_dict):
     assert float((shifted[0] - base[0]).abs().max()) > 1.0                  # a different function, not a rounding difference
     with pytest.raises(KeyError):
         O.variant(no_such_switch=1)
+
+
+@pytest.mark.parametrize("H,W", [(64, 256), (63, 255)])
+def test_c_oracle_follows_the_align_mode_switch(state_dict, H, W):
+    """lws_config.interp_align_mode's checker: the C restatement's resizes read oracle.lws_oracle.VARIANT["align_mode"]
+    (c_oracle._sync_align_mode -> lwso_set_align_mode), so `with variant(align_mode=1)` moves BOTH restatements together.
+    Under mode 1 the two agree as closely as under mode 0 (float32 noise of two summation orders), the resize itself is
+    bit-identical between them, and mode 0 is back -- in the C library too -- once the block exits."""
+    left, right, _ = make_pair(H, W, 5)
+    x = np.random.default_rng(2).standard_normal((2, 1, 16, 32)).astype(np.float32)
+    with O.variant(align_mode=1):
+        lit = O.forward(left[None], right[None], state_dict)
+        cst = C.forward(left[None], right[None], state_dict)
+        assert C.lib().lwso_get_align_mode() == 1
+        for size in ((8, 16), (32, 64), (128, 256)):                        # integer ratios: the same taps and weights exactly
+            assert np.array_equal(C.resize_bilinear(x, *size), O.interp_bilinear(torch.from_numpy(x), size, 1).numpy())
+    base = C.forward(left[None], right[None], state_dict)
+    assert C.lib().lwso_get_align_mode() == 0
+    for s in range(4):
+        assert float(np.abs(cst[s] - lit[s].numpy()).max()) < 2e-2, s
+    assert float(np.abs(cst[3] - base[3]).max()) > 0.05                     # the other reading is a different function

@@ -79,6 +79,9 @@ nn.initializer.KaimingNormal = _b.KaimingNormal
 nn.functional = types.ModuleType("paddle.nn.functional")
 for _n in ("relu", "softmax", "interpolate", "grid_sample"):
     setattr(nn.functional, _n, getattr(_b, _n))
+import os as _os
+if _os.environ.get("LWS_FAKE_PADDLE_ALIGN_MODE") == "1":        # a Paddle whose F.interpolate defaults to align_mode = 1
+    nn.functional.interpolate = lambda x, size=None, mode="nearest", align_corners=False: _b.interpolate(x, size, mode, align_corners, align_mode=1)
 sys.modules.update({"paddle.nn": nn, "paddle.nn.initializer": nn.initializer, "paddle.nn.functional": nn.functional})
 '''
 
@@ -105,6 +108,15 @@ def test_real_paddle_mode_with_a_fake_paddle_package(tmp_path):
     assert "0.0-fake-for-tests" in p.stdout and "stand-in NOT installed" in p.stdout
     assert p.stdout.count("INSIDE the gate") == 5 and p.stdout.count("(bit-equal)") == 5, p.stdout
     assert "all equal to what was set" in p.stdout and "parity with PaddlePaddle holds" in p.stdout
+    assert "follows align_mode = 0 (half-pixel centres) on every case" in p.stdout
+    # a Paddle that resizes with src = ratio * dst (the one bet of the oracle that would move every stage): the mode names the
+    # reading it matches and what to flip, exit status 3
+    env["LWS_FAKE_PADDLE_ALIGN_MODE"] = "1"
+    p = subprocess.run([sys.executable, "-B", tool, "--reference", REF, "--real-paddle"], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert p.returncode == 3, (p.stdout[-3000:], p.stderr[-3000:])
+    assert "follows align_mode = 1 (src = ratio * dst) on every case" in p.stdout and "interp_align_mode = 1" in p.stdout
+    assert p.stdout.count("align_mode 1: ") == 5 and p.stdout.count("-> INSIDE") == 5 and p.stdout.count("OUTSIDE the gate") == 5
     # the kept file is what the product's loader reads for inference.py:45
     from lwsnet_amd import checkpoint
     from lwsnet_amd.weights import default_args, make_state_dict
