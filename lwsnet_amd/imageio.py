@@ -52,14 +52,22 @@ def jet_lut():
     return np.stack([ramp(-382, 1148), ramp(-128, 892), ramp(128, 638)], 1).astype(np.uint8)
 
 
+_JET = None
+
+
 def disparity_to_color(disp):
     """inference.py:114-115: `.astype(np.uint8)` (C cast: truncation, wrap-around outside 0..255) then JET."""
+    global _JET
+    if _JET is None:
+        _JET = jet_lut()
     d8 = np.asarray(disp, dtype=np.float32).astype(np.int64).astype(np.uint8)
-    return jet_lut()[d8]
+    return _JET[d8]
 
 
 def save_png(path, rgb):
-    Image.fromarray(rgb).save(path)
+    """inference.py:120,136 `cv2.imwrite(path, img)`: OpenCV's PNG default is compression level 1 (best speed); so is this.
+    (Lossless either way: the pixels are what is compared, tests/test_gpu_parity.py::test_config1_*.)"""
+    Image.fromarray(rgb).save(path, compress_level=1)
 
 
 def read_pfm(path):

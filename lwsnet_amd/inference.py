@@ -10,9 +10,10 @@ after a device synchronise and excludes the first (warm-up) call; `--vis` is acc
 
 `--workers N` (not in the reference; directory mode only): the reference's loop (inference.py:88-137) is one pair at a time --
 decode, forward, colour-map, encode, all on one thread, which is what its published "10 FPS" measures.  With N > 0 the same
-per-pair work is pipelined: N host threads decode / crop / normalise into pinned buffers, a copy stream uploads them, the
-forwards run through lws_pool (several batch-1 forwards in flight), a second copy stream brings the stage-4 maps back and N
-host threads colour-map and PNG-encode them.  The files written are byte-identical to the sequential loop's
+per-pair work is pipelined: N host worker PROCESSES (spawned, numpy + PIL only, no GPU) decode / crop / normalise into
+shared-memory slots that are registered with HIP as pinned memory, a copy stream uploads them, the forwards run through lws_pool
+(several batch-1 forwards in flight), a second copy stream brings the stage-4 maps back into the slot and the same workers
+colour-map and PNG-encode them.  The files written are byte-identical to the sequential loop's
 (tests/test_gpu_parity.py::test_cli_directory_pipeline_writes_identical_files); the end-to-end rate and where the time goes
 are logged and returned (profiles/r06/e2e_cli.txt).
 """
@@ -46,29 +47,105 @@ def build_parser():
                    help="opt-in numerics mode of this build (not in the reference): MFMA convolutions on split-bf16 operands, "
                         "float32-level accuracy, +20-25 %% speed, not bit-identical to the default (include/lwsnet_hip.h)")
     p.add_argument("--workers", type=int, default=0,
-                   help="directory mode: host threads for decode and for encode around a pipelined GPU path (0 = the reference's "
-                        "sequential loop; not in the reference)")
+                   help="directory mode: host worker processes for decode and encode around a pipelined GPU path (0 = the "
+                        "reference's sequential loop; not in the reference)")
     p.add_argument("--gpu_workers", type=int, default=3, help="with --workers: forwards kept in flight by lws_pool")
     return p
 
 
+def _host_worker(task_q, done_q, slot_names, H, W):
+    """Body of a host worker PROCESS of the pipelined directory mode (spawned: a fresh interpreter that imports numpy and PIL
+    only and never touches the GPU).  Tasks: ("decode", i, slot, left path, right path) -> decode, crop, normalise both images
+    into the slot's shared memory (inference.py:90-103); ("encode", i, slot, out path) -> uint8 cast, JET, PNG of the slot's
+    stage-4 map (inference.py:114-115,136).  Python threads do this work at most ~16-wide (the interpreter lock); processes
+    scale with the host's cores."""
+    from multiprocessing import shared_memory
+
+    from lwsnet_amd import imageio as io
+    n_in = 3 * H * W
+    shms = {}
+
+    def views(sid):
+        if sid not in shms:
+            shm = shared_memory.SharedMemory(name=slot_names[sid])
+            buf = np.ndarray((2 * n_in + H * W,), np.float32, buffer=shm.buf)
+            shms[sid] = (shm, buf[:n_in].reshape(3, H, W), buf[n_in:2 * n_in].reshape(3, H, W), buf[2 * n_in:].reshape(H, W))
+        return shms[sid]
+
+    while True:
+        task = task_q.get()
+        if task is None:
+            break
+        kind, i, sid = task[0], task[1], task[2]
+        t0 = time.perf_counter()
+        try:
+            if kind == "decode":
+                left = io.crop_bottom_right(io.load_rgb(task[3]))
+                right = io.crop_bottom_right(io.load_rgb(task[4]))
+                if left is None or right is None:                       # inference.py:96-97
+                    done_q.put(("skipped", i, sid, 0.0))
+                    continue
+                _, vl, vr, _ = views(sid)
+                np.copyto(vl, io.to_input(left))
+                np.copyto(vr, io.to_input(right))
+                done_q.put(("decoded", i, sid, time.perf_counter() - t0))
+            else:
+                io.save_png(task[3], io.disparity_to_color(views(sid)[3]))
+                done_q.put(("encoded", i, sid, time.perf_counter() - t0))
+        except Exception as e:                                          # noqa: BLE001 (reported to the parent, which raises)
+            done_q.put(("error", i, sid, f"{kind} of pair {i}: {type(e).__name__}: {e}"))
+    for shm, *_ in shms.values():
+        shm.close()
+
+
 class _Slot:
-    """Buffers of one pair in flight: pinned host inputs, device inputs, device stage maps, pinned stage-4 map."""
+    """Buffers of one pair in flight: a shared-memory block [left | right | stage-4 map] the host workers read and write,
+    registered with HIP as pinned memory when the runtime allows (otherwise staged through pinned tensors), device inputs and
+    the four device stage maps."""
 
     def __init__(self, dev, H, W):
+        from multiprocessing import shared_memory
+
         import torch
-        self.pin_l = torch.empty((1, 3, H, W), dtype=torch.float32).pin_memory()
-        self.pin_r = torch.empty((1, 3, H, W), dtype=torch.float32).pin_memory()
+        n_in = 3 * H * W
+        self.shm = shared_memory.SharedMemory(create=True, size=4 * (2 * n_in + H * W))
+        host = torch.frombuffer(self.shm.buf, dtype=torch.float32)
+        self.registered = False
+        try:
+            rc = torch.cuda.cudart().cudaHostRegister(host.data_ptr(), host.numel() * 4, 0)
+            self.registered = (rc == 0 or int(rc) == 0) and host.is_pinned()
+        except Exception:                                               # noqa: BLE001 (fall back to staging copies)
+            self.registered = False
+        self.host_l, self.host_r, self.host_out = host[:n_in].view(1, 3, H, W), host[n_in:2 * n_in].view(1, 3, H, W), host[2 * n_in:].view(H, W)
+        if not self.registered:
+            self.pin_l = torch.empty((1, 3, H, W), dtype=torch.float32).pin_memory()
+            self.pin_r = torch.empty((1, 3, H, W), dtype=torch.float32).pin_memory()
+            self.pin_out = torch.empty((H, W), dtype=torch.float32).pin_memory()
         self.dev_l = torch.empty((1, 3, H, W), dtype=torch.float32, device=dev)
         self.dev_r = torch.empty((1, 3, H, W), dtype=torch.float32, device=dev)
         self.outs = [torch.empty((1, 1, H, W), dtype=torch.float32, device=dev) for _ in range(4)]
-        self.pin_out = torch.empty((H, W), dtype=torch.float32).pin_memory()
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]      # h2d begin / end, d2h begin / end
+        self.t0 = 0.0
+
+    def close(self):
+        import torch
+        ptr = self.host_l.data_ptr()
+        self.host_l = self.host_r = self.host_out = None
+        if self.registered:
+            try:
+                torch.cuda.cudart().cudaHostUnregister(ptr)
+            except Exception:                                           # noqa: BLE001
+                pass
+        try:
+            self.shm.close()
+        except BufferError:                                             # a view is still alive somewhere: unlink anyway
+            pass
+        self.shm.unlink()
 
 
 def inference_pipelined(model, left_imgs, right_imgs, args, log):
     """The loop of inference.py:88-137 in directory mode, pipelined (see the module docstring).  Returns (written, stats)."""
-    import concurrent.futures as cf
+    import multiprocessing as mp
     import queue
     import threading
 
@@ -77,114 +154,122 @@ def inference_pipelined(model, left_imgs, right_imgs, args, log):
     dev = model.device
     N, P = max(1, int(args.workers)), max(1, int(args.gpu_workers))
     H, W = io.CROP_H, io.CROP_W
-    nslots = 2 * P + N
+    total = len(left_imgs)
     torch.cuda.set_device(dev)
-    slots = [_Slot(dev, H, W) for _ in range(nslots)]
+    slots = [_Slot(dev, H, W) for _ in range(2 * P + 2 * N)]
+    ctx = mp.get_context("spawn")                        # fresh interpreters: a forked child of a process that holds HIP state is not safe
+    task_q, done_q = ctx.Queue(), ctx.Queue()
+    names = [sl.shm.name for sl in slots]
+    procs = [ctx.Process(target=_host_worker, args=(task_q, done_q, names, H, W), daemon=True) for _ in range(N)]
+    for pr in procs:
+        pr.start()
     free = queue.Queue()
-    for sl in slots:
-        free.put(sl)
-    ready, inflight = queue.Queue(), queue.Queue()
-    written, lock = {}, threading.Lock()
+    for sid in range(len(slots)):
+        free.put(sid)
+    inflight = queue.Queue()
+    written = {}
     acc = {"decode_s": 0.0, "encode_s": 0.0, "h2d_ms": 0.0, "d2h_ms": 0.0, "pairs": 0, "skipped": 0, "latency_s": 0.0}
     errors = []
     h2d, d2h = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    finished = threading.Event()
 
-    def decode(i, sl):
-        try:
-            t0 = time.perf_counter()
-            left = io.crop_bottom_right(io.load_rgb(left_imgs[i]))
-            right = io.crop_bottom_right(io.load_rgb(right_imgs[i]))
-            if left is None or right is None:                           # inference.py:96-97
-                with lock:
-                    acc["skipped"] += 1
-                free.put(sl)
-                ready.put(None)
-                return
-            np.copyto(sl.pin_l.numpy()[0], io.to_input(left))
-            np.copyto(sl.pin_r.numpy()[0], io.to_input(right))
-            with lock:
-                acc["decode_s"] += time.perf_counter() - t0
-            ready.put((i, sl, t0))
-        except Exception as e:                                          # noqa: BLE001 (re-raised by the caller)
-            errors.append(e)
-            ready.put(None)
+    def feeder():
+        for i in range(total):
+            sid = free.get()
+            slots[sid].t0 = time.perf_counter()
+            task_q.put(("decode", i, sid, left_imgs[i], right_imgs[i]))
 
-    def encode(i, sl, t_start):
-        try:
-            t0 = time.perf_counter()
-            color = io.disparity_to_color(sl.pin_out.numpy())
-            path = os.path.join(args.save_path, os.path.basename(left_imgs[i]))
-            io.save_png(path, color)
-            t1 = time.perf_counter()
-            with lock:
-                acc["encode_s"] += t1 - t0
-                acc["h2d_ms"] += sl.ev[0].elapsed_time(sl.ev[1])
-                acc["d2h_ms"] += sl.ev[2].elapsed_time(sl.ev[3])
-                acc["pairs"] += 1
-                acc["latency_s"] += t1 - t_start
-                written[i] = path
-            free.put(sl)
-        except Exception as e:                                          # noqa: BLE001
-            errors.append(e)
-            free.put(sl)
-
-    def feeder(pool_):
-        for i in range(len(left_imgs)):
-            sl = free.get()
-            pool_.submit(decode, i, sl)
-
-    def collector(enc_pool):
+    def collector():
         torch.cuda.set_device(dev)
         while True:
             item = inflight.get()
             if item is None:
                 return
-            i, sl, job, t0 = item
+            i, sid, job = item
+            sl = slots[sid]
             try:
                 job.result()                                            # the four stage maps are complete in device memory
+                dst = sl.host_out if sl.registered else sl.pin_out
                 with torch.cuda.stream(d2h):
                     sl.ev[2].record()
-                    sl.pin_out.copy_(sl.outs[3][0, 0], non_blocking=True)   # directory mode keeps the stage-4 map only (:133-137)
+                    dst.copy_(sl.outs[3][0, 0], non_blocking=True)      # directory mode keeps the stage-4 map only (:133-137)
                     sl.ev[3].record()
                 sl.ev[3].synchronize()
-                enc_pool.submit(encode, i, sl, t0)
+                if not sl.registered:
+                    sl.host_out.copy_(sl.pin_out)
+                task_q.put(("encode", i, sid, os.path.join(args.save_path, os.path.basename(left_imgs[i]))))
             except Exception as e:                                      # noqa: BLE001
                 errors.append(e)
-                free.put(sl)
+                done_q.put(("error", i, sid, repr(e)))
 
-    # warm-up outside the clock (the reference times its first call; this build never does): one forward, library and pool up
-    with model.pool(workers=P) as gpool:
-        gpool.reserve(1, H, W)
-        gpool.submit(slots[0].dev_l.zero_(), slots[0].dev_r.zero_(), out=slots[0].outs).result()
-        torch.cuda.synchronize(dev)
-        t_begin = time.perf_counter()
-        with cf.ThreadPoolExecutor(N, thread_name_prefix="lws-decode") as dec_pool, \
-                cf.ThreadPoolExecutor(N, thread_name_prefix="lws-encode") as enc_pool:
-            tf = threading.Thread(target=feeder, args=(dec_pool,), daemon=True)
-            tc = threading.Thread(target=collector, args=(enc_pool,), daemon=True)
+    try:
+        # warm-up outside the clock (the reference times its first call; this build never does): library, pool and workers up
+        with model.pool(workers=P) as gpool:
+            gpool.reserve(1, H, W)
+            gpool.submit(slots[0].dev_l.zero_(), slots[0].dev_r.zero_(), out=slots[0].outs).result()
+            torch.cuda.synchronize(dev)
+            t_begin = time.perf_counter()
+            tf = threading.Thread(target=feeder, daemon=True)
+            tc = threading.Thread(target=collector, daemon=True)
             tf.start()
             tc.start()
-            for _ in range(len(left_imgs)):
-                item = ready.get()
-                if item is None:
+            done = 0
+            while done < total and not errors:
+                try:
+                    kind, i, sid, val = done_q.get(timeout=5.0)
+                except queue.Empty:
+                    if not all(pr.is_alive() for pr in procs):
+                        errors.append(RuntimeError("a host worker process died"))
                     continue
-                i, sl, t0 = item
-                with torch.cuda.stream(h2d):
-                    sl.ev[0].record()
-                    sl.dev_l.copy_(sl.pin_l, non_blocking=True)
-                    sl.dev_r.copy_(sl.pin_r, non_blocking=True)
-                    sl.ev[1].record()
-                    job = gpool.submit(sl.dev_l, sl.dev_r, out=sl.outs)     # starts behind the copies (after_stream = h2d)
-                inflight.put((i, sl, job, t0))
+                sl = slots[sid]
+                if kind == "decoded":
+                    acc["decode_s"] += val
+                    src_l, src_r = (sl.host_l, sl.host_r) if sl.registered else (sl.pin_l, sl.pin_r)
+                    if not sl.registered:
+                        sl.pin_l.copy_(sl.host_l)
+                        sl.pin_r.copy_(sl.host_r)
+                    with torch.cuda.stream(h2d):
+                        sl.ev[0].record()
+                        sl.dev_l.copy_(src_l, non_blocking=True)
+                        sl.dev_r.copy_(src_r, non_blocking=True)
+                        sl.ev[1].record()
+                        job = gpool.submit(sl.dev_l, sl.dev_r, out=sl.outs)     # starts behind the copies (after_stream = h2d)
+                    inflight.put((i, sid, job))
+                elif kind == "encoded":
+                    acc["encode_s"] += val
+                    acc["h2d_ms"] += sl.ev[0].elapsed_time(sl.ev[1])
+                    acc["d2h_ms"] += sl.ev[2].elapsed_time(sl.ev[3])
+                    acc["pairs"] += 1
+                    acc["latency_s"] += time.perf_counter() - sl.t0
+                    written[i] = os.path.join(args.save_path, os.path.basename(left_imgs[i]))
+                    free.put(sid)
+                    done += 1
+                elif kind == "skipped":
+                    acc["skipped"] += 1
+                    free.put(sid)
+                    done += 1
+                else:
+                    errors.append(RuntimeError(val))
+            wall = time.perf_counter() - t_begin
             inflight.put(None)
-            tf.join()
-            tc.join()
-        wall = time.perf_counter() - t_begin                                # (the executors' exit waits for the last encode)
+            finished.set()
+            tc.join(timeout=30.0)
+    finally:
+        for _ in procs:
+            task_q.put(None)
+        for pr in procs:
+            pr.join(timeout=10.0)
+            if pr.is_alive():
+                pr.terminate()                                          # (the exact children started above)
+        registered = all(sl.registered for sl in slots)
+        torch.cuda.synchronize(dev)
+        for sl in slots:
+            sl.close()
     if errors:
         raise errors[0]
     n = max(acc["pairs"], 1)
     stats = {"pairs": acc["pairs"], "skipped": acc["skipped"], "wall_s": round(wall, 4), "pairs_per_s": round(acc["pairs"] / wall, 2),
-             "host_threads": N, "gpu_workers": P,
+             "host_processes": N, "gpu_workers": P, "shared_memory_pinned": registered,
              "decode_ms_per_pair": round(1e3 * acc["decode_s"] / n, 3), "encode_ms_per_pair": round(1e3 * acc["encode_s"] / n, 3),
              "h2d_ms_per_pair": round(acc["h2d_ms"] / n, 3), "d2h_ms_per_pair": round(acc["d2h_ms"] / n, 3),
              "latency_ms_per_pair": round(1e3 * acc["latency_s"] / n, 2)}

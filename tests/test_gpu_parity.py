@@ -1209,8 +1209,9 @@ def test_profiler_counts_and_sampling(dev, model, hip_lib):
 
 def test_cli_directory_pipeline_writes_identical_files(dev, hip_lib, tmp_path):
     """`python -m lwsnet_amd.inference --img_path DIR --workers N`: the reference's directory loop
-    (/root/reference/inference.py:50-63,88-137) pipelined -- host threads decode into pinned buffers, a copy stream uploads,
-    lws_pool keeps forwards in flight, the stage-4 maps come back on a second copy stream, host threads colour-map and encode.
+    (/root/reference/inference.py:50-63,88-137) pipelined -- host worker processes decode into shared-memory slots (pinned when
+    HIP can register them), a copy stream uploads, lws_pool keeps forwards in flight, the stage-4 maps come back on a second copy
+    stream, the workers colour-map and encode.
     Twelve distinct pairs (the reference's KITTI pair, shifted) plus one image that is too small (skipped, inference.py:96-97):
     the files are byte-identical to the sequential loop's, for two worker counts."""
     from PIL import Image

@@ -6,7 +6,7 @@
 Builds a KITTI-style folder (image_2/ + image_3/) from the reference's own pair (tests/golden/kitti_pair/, BASELINE config 1)
 -- every copy shifted by a few columns so that no two files hold the same image -- and runs the loop of
 `python -m lwsnet_amd.inference --img_path DIR` over it: once sequentially (the reference's loop: one pair at a time on one
-thread, which is what its published "10 FPS" measures) and once per --workers value through the pipelined path.  Prints pairs/s
+thread, which is what its published "10 FPS" measures) and once per --workers value (host worker processes) through the pipelined path.  Prints pairs/s
 end to end (decode -> PNG on disk) and where the time goes; checks that every pipelined run wrote byte-identical files.
 Seeded synthetic weights (the reference ships no checkpoint)."""
 import argparse
@@ -86,7 +86,7 @@ def main():
             torch.cuda.synchronize()
             ts.append(1e3 * (time.perf_counter() - t1))
         print(f"isolated forward 1 x 368x1232 (host call -> stream idle): median {sorted(ts)[15]:.3f} ms")
-        print("workers gpu_workers pairs/s  vs_seq  decode_ms encode_ms h2d_ms d2h_ms latency_ms files_identical")
+        print("workers gpu_workers pairs/s  vs_seq  decode_ms encode_ms h2d_ms d2h_ms latency_ms shm_pinned files_identical")
         for w in a.workers:
             args.workers, args.gpu_workers = w, a.gpu_workers
             args.save_path = os.path.join(tmp, f"out_w{w}")
@@ -94,10 +94,10 @@ def main():
             _, st = inf.inference_pipelined(model, lefts, rights, args, log)
             n, d = digest(args.save_path)
             print(f"{w:7d} {a.gpu_workers:11d} {st['pairs_per_s']:7.1f} {st['pairs_per_s'] * seq / a.pairs:6.2f}x {st['decode_ms_per_pair']:9.2f} "
-                  f"{st['encode_ms_per_pair']:9.2f} {st['h2d_ms_per_pair']:6.3f} {st['d2h_ms_per_pair']:6.3f} {st['latency_ms_per_pair']:10.1f} "
+                  f"{st['encode_ms_per_pair']:9.2f} {st['h2d_ms_per_pair']:6.3f} {st['d2h_ms_per_pair']:6.3f} {st['latency_ms_per_pair']:10.1f} {str(st['shared_memory_pinned']):>10s} "
                   f"{n == nseq and d == dseq}")
             shutil.rmtree(args.save_path)
-        print("# decode / encode: host thread time per pair (PIL decode + crop + normalise; uint8 cast + JET + PNG encode); h2d / d2h: "
+        print("# workers = host worker processes; decode / encode: their time per pair (PIL decode + crop + normalise; uint8 cast + JET + PNG encode); h2d / d2h: "
               "hipEvent-timed copies per pair (2 x 5.4 MB up, 1.8 MB down); latency: decode start -> file on disk")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
