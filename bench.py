@@ -685,7 +685,11 @@ def worker(args):
     # (refinement2's last block runs inside k_ref_dws_last -- class ref_last -- at batch 1: option "fuse_ref_last")
     frl = model.get_option("fuse_ref_last")
     dws_blocks = 11 if (frl == 1 or (frl == -1 and B <= 1)) else 12
-    for name, step_bytes in (("volume_l1_warp", float(sum(warp_bytes))), ("ref_dws", dws_blocks * 2.0 * B * H * W * 32 * 4),
+    # (the first block of each refinement1 branch reads its 1- or 3-plane input instead of a 32-channel map when the branch's first
+    # convolution runs inside it: option "fuse_first")
+    ff = model.get_option("fuse_first")
+    dws_bytes = (dws_blocks * 2.0 * 32 - ((32 - 1) if ff & 1 else 0) - ((32 - 3) if ff & 2 else 0)) * B * H * W * 4
+    for name, step_bytes in (("volume_l1_warp", float(sum(warp_bytes))), ("ref_dws", dws_bytes),
                              ("softargmin", (margs.maxdisplist[0] * (h2 // 4) * (w2 // 4) + H * W) * 4.0 * B),
                              ("conv3d_first", first_bytes), ("conv3d_last", last_bytes)):
         if name in kernels:

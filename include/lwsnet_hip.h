@@ -143,10 +143,9 @@ int lws_forward(lws_handle h, const float *left, const float *right, int B, int 
  * the opt-in numerics mode "split_bf16".  (ABI v8 removed the options two rounds of sweeps had retired: left_at, split_heads,
  * fuse_shift, conv3d_order, mid8_tile, mid8_balance, fork_ext, tail_at, and folded mid8_form / mid16_form / conv64_form into
  * "split_bf16"; what was measured against what is in profiles/NOTES.md.)
- *   "fuse_first"     bit mask, 1 (default): bit 0 = refinement1_disp's 1 -> 32 convolution, bit 1 = refinement1_left's 3 -> 32
- *                    convolution inside their first depthwise blocks (one launch and one 32-channel map less each; bit 1
- *                    measured neutral at every batch in round 6 -- the recomputed 27-tap convolution costs the block what the
- *                    launch and the map cost the stream -- hence off by default)
+ *   "fuse_first"     bit mask, 3 (default): bit 0 = refinement1_disp's 1 -> 32 convolution, bit 1 = refinement1_left's 3 -> 32
+ *                    convolution inside their first depthwise blocks (k_ref_dws<CIN>: the convolution recomputed on the halo
+ *                    tile on fp32 MFMA; one launch and one 32-channel map less each)
  *   "defer_upsample" 1 (default) = at batches <= 2 the consumers evaluate the stage-2/3 maps
  *   "split_bf16"     0 (default) or a bit mask: 1 = the 32 -> 32 Conv3D layers (k_conv3d_mid16x), 2 = the 8 -> 8 Conv3D layers
  *                    of stages 2, 3 (k_conv3d_mid8x; samples under 256 tiles stay on the exact kernel), 4 = refinement2[0]

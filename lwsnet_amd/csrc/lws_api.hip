@@ -295,7 +295,7 @@ struct SlabBuilder {
 struct Net2dOffsets {
     struct L { size_t w, wp, wm, s, t; bool bn; };
     L fe[12];
-    size_t r1_first[2];
+    size_t r1_first[2], r1_first_mfma[2];
     struct D { size_t s, t, dw, pw; };
     D r1[2][4], r2[4];
     size_t r2f_s, r2f_t, r2f_w, r2f_wx, r2_last;
@@ -386,6 +386,9 @@ static void build_net2d(const lws_ctx *h, std::vector<float> &slab, Net2dOffsets
             for (int ci = 0; ci < cin; ++ci)
                 for (int tap = 0; tap < 9; ++tap) wt[(tap * cin + ci) * 32 + co] = w[(co * cin + ci) * 9 + tap];
         o.r1_first[k] = sb.put(wt);
+        std::vector<float> wf(packed_first_mfma_floats(cin));
+        pack_first_mfma(w.data(), cin, wf.data());
+        o.r1_first_mfma[k] = sb.put(wf);
         for (int b = 0; b < 4; ++b) pack_dws(h, sb, std::string(r1n[k]) + "." + std::to_string(b + 1), o.r1[k][b]);
     }
     {
@@ -431,6 +434,7 @@ static void bind_net2d(lws_ctx *h, const Net2dOffsets &o)
     };
     for (int k = 0; k < 2; ++k) {
         n.r1_first[k] = h->params + o.r1_first[k];
+        n.r1_first_mfma[k] = h->params + o.r1_first_mfma[k];
         for (int b = 0; b < 4; ++b) bind_dws(n.r1[k][b], o.r1[k][b], 2 << b);      // dilation 2,4,8,16 (submodules.py:298)
     }
     n.r2_first.bn_s = h->params + o.r2f_s;
@@ -554,7 +558,7 @@ static int refine_left_chunk(lws_ctx *h, const float *left, int B, int H, int W,
     if ((h->opt.fuse_first & 2) && ref_first_dws_can_fuse(n.r1[0][0], 3)) {
         // the 3 -> 32 convolution is recomputed inside the first block's staging: one launch less, and the 32-channel map
         // it would write (and the block read back) never exists
-        LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[0][0], left, 3, n.r1_first[0], rc_, B, H, W, st));
+        LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[0][0], left, 3, n.r1_first_mfma[0], rc_, B, H, W, st));
     } else {
         LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(left, 3, n.r1_first[0], ra, B, H, W, st));
         LWS_RF(LWS_KC_REF_DWS, launch_ref_dws(n.r1[0][0], ra, rc_, B, H, W, st));
@@ -641,10 +645,10 @@ static int refine_rest_chunk(lws_ctx *h, float *pred3, int B, int H, int W, cons
         // refinement1_disp: the 1 -> 32 convolution is recomputed inside the first block's staging (one launch less)
         if (ds != nullptr && ds->def[2]) {
             // pred3 = upsample(low[2]) + pred2 was not materialised: this kernel evaluates it and writes it out
-            LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[1][0], pred2, 1, n.r1_first[1], rc_, B, H, W, st, ds->low[2],
+            LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[1][0], pred2, 1, n.r1_first_mfma[1], rc_, B, H, W, st, ds->low[2],
                                                         ds->lh[2], ds->lw[2], pred3, ioff_of(h)));
         } else {
-            LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[1][0], pred3, 1, n.r1_first[1], rc_, B, H, W, st));
+            LWS_RF(LWS_KC_REF_DWS, launch_ref_first_dws(n.r1[1][0], pred3, 1, n.r1_first_mfma[1], rc_, B, H, W, st));
         }
     } else {
         LWS_RF(LWS_KC_REF_FIRST, launch_ref_first(pred3, 1, n.r1_first[1], rb, B, H, W, st));

@@ -200,6 +200,7 @@ struct RefConv64 {
 struct Net2d {
     Conv2dLayer fe[12];          // feature extractor, in execution order
     float *r1_first[2] = {nullptr, nullptr};   // refinement1_left / _disp first conv, [tap][cin][32]
+    float *r1_first_mfma[2] = {nullptr, nullptr};   // ... as A fragments for first_conv_mfma, [mt][j][lane]
     RefDws r1[2][4];             // refinement1_{left,disp} blocks 1..4
     RefConv64 r2_first;
     RefDws r2[4];
@@ -217,7 +218,7 @@ struct lws_ctx {
     lws_config cfg;
     // schedule options (lws_set_option): every setting computes the same bits, only the launch plan differs
     struct {
-        int fuse_first = 1;        // bit 0: refinement1_disp's 1 -> 32, bit 1: refinement1_left's 3 -> 32 convolution inside their first depthwise blocks
+        int fuse_first = 3;        // bit 0: refinement1_disp's 1 -> 32, bit 1: refinement1_left's 3 -> 32 convolution inside their first depthwise blocks
         int defer_upsample = 1;    // batches <= 2: consumers evaluate the stage-2/3 maps (no k_upsample_add launches)
         int side_streams = 1;      // 0: no handle-owned side stream, the whole forward on the caller's stream (lws_pool workers)
         int split_bf16 = 0;        // bit mask of the MFMA convolutions on split-bf16 operands (NOT bit-exact): 1 = Conv3D 32 -> 32, 2 = Conv3D 8 -> 8, 4 = refinement2[0]
@@ -298,9 +299,11 @@ int launch_conv2d_pair(const Conv2dLayer &a, const Conv2dLayer &b, const float *
 int launch_ref_first(const float *in, int cin, const float *w, float *out, int B, int H, int W, hipStream_t st);
 int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, int W, hipStream_t st);
 bool ref_first_dws_can_fuse(const RefDws &l, int cin);
-int launch_ref_first_dws(const RefDws &l, const float *img, int cin, const float *wfirst, float *out, int B, int H, int W,
+int launch_ref_first_dws(const RefDws &l, const float *img, int cin, const float *wfrag, float *out, int B, int H, int W,
                          hipStream_t st, const float *plow = nullptr, int ph = 0, int pw = 0, float *pmat = nullptr,
                          float ioff = 0.5f);
+int packed_first_mfma_floats(int cin);
+void pack_first_mfma(const float *w /*[32][cin][3][3]*/, int cin, float *out);
 int launch_ref_conv64(const RefConv64 &l, const float *inL, const float *inD, float *out, int B, int H, int W,
                       hipStream_t st);
 int launch_ref_last(const float *in, const float *w, const float *pred3, float *out, int B, int H, int W, hipStream_t st);

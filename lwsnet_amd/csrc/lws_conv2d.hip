@@ -645,13 +645,67 @@ __device__ __forceinline__ RefTile ref_tile(int dil, int nbx, int nby, int tile_
 constexpr int DWS_SA = 186, DWS_SB = 130;
 
 // FIRST = CIN > 0 fuses the CIN -> 32 convolution in front of the block (refinement1_disp[0] with CIN = 1, refinement1_left[0]
-// with CIN = 3, submodules.py:282-300: 3x3, pad 1, no BN/ReLU) into the staging: `in` is then the [B,CIN,H,W] image and wf its
-// [tap][cin][32] weights; every halo pixel's 32 channels are recomputed from a dense (RH_Y-1)*dil+3 x (RH_X-1)*dil+3 window of
-// every input plane held in LDS (aliased onto sB, which is not live yet) with the same fmaf chain as k_ref_first -- taps
-// ascending, input channel inner.  Requires dil = 2.  The 32-channel map the separate launch would write and this block read
-// back (128 B per pixel each way) never exists.
+// with CIN = 3, submodules.py:282-300: 3x3, pad 1, no BN/ReLU) into the staging: `in` is then the [B,CIN,H,W] image and wf the
+// convolution's MFMA A fragments (pack_first_mfma); every halo pixel's 32 channels are recomputed from a dense
+// (RH_Y-1)*dil+3 x (RH_X-1)*dil+3 window of every input plane held in LDS (aliased onto sB, which is not live yet) with the same
+// fmaf chain as k_ref_first -- taps ascending, input channel inner (first_conv_mfma).  Requires dil = 2.  The 32-channel map the
+// separate launch would write and this block read back (128 B per pixel each way) never exists.
+// (Round 4 built the CIN = 1 form on packed FMA, round 6 the CIN = 3 form likewise: neutral; on MFMA both pay -- profiles/NOTES.md.)
 constexpr int DWS_FD = 2, DWS_FR = (RH_Y - 1) * DWS_FD + 3, DWS_FC = (RH_X - 1) * DWS_FD + 3;
 static_assert(DWS_FR * DWS_FC <= 1024 && 3 * DWS_FR * DWS_FC <= 8 * DWS_SB * 4, "first-conv window must fit 4 loads/thread/plane and sB");
+
+// The fused CIN -> 32 convolution on fp32 MFMA: Out^T[cout, halo pixel] = W[cout, k] X[k, pixel] with k = 3 tap + ci (taps
+// ascending, input channel inner: k_ref_first's chain, which v_mfma_f32_16x16x4_f32 reproduces k by k), K = 9 CIN padded to a
+// multiple of 4 with zero weights (fmaf(x, 0, acc) == acc).  The 180 halo pixels are 12 N-tiles of 16, three per wave; lane
+// (n, g) of MFMA j supplies window value k = 4 j + g of pixel n -- one ds_read_b32 at a per-lane offset, shared by the two
+// output-channel tiles -- and ends up with channels 16 mt + 4 g .. + 3 of pixel n: exactly one float4 slot of sA.
+template <int CIN>
+__device__ __forceinline__ void first_conv_mfma(const float *sImg, const float *__restrict__ wfrag,   // [mt][j][lane]
+                                                const float *__restrict__ bn_s, const float *__restrict__ bn_t, float4 *sA,
+                                                int Y0, int X0, int H, int W, int lane, int wave)
+{
+    constexpr int WIN = DWS_FR * DWS_FC, K = 9 * CIN, J = (K + 3) / 4, NPX = RH_Y * RH_X, NTW = 3;
+    static_assert(4 * NTW * 16 >= NPX, "three N-tiles per wave must cover the halo tile");
+    const int n = lane & 15, g = lane >> 4;
+    float a[2][J];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < J; ++j) a[mt][j] = wfrag[(mt * J + j) * 64 + lane];
+    int koff[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = 4 * j + g, tap = k / CIN, ci = k - tap * CIN, kh = tap / 3, kw = tap - kh * 3;
+        koff[j] = k < K ? ci * WIN + kh * DWS_FC + kw : 0;
+    }
+    float4 s4[2], t4[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        s4[mt] = *reinterpret_cast<const float4 *>(bn_s + (mt * 4 + g) * 4);
+        t4[mt] = *reinterpret_cast<const float4 *>(bn_t + (mt * 4 + g) * 4);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int hp = (wave * NTW + nt) * 16 + n;
+        const int hy = hp / RH_X, hx = hp - hy * RH_X;
+        const float *sp = sImg + (hp < NPX ? (hy * DWS_FD) * DWS_FC + hx * DWS_FD : 0);
+        floatx4 acc[2] = {(floatx4){0.f, 0.f, 0.f, 0.f}, (floatx4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float b = sp[koff[j]];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], b, acc[mt], 0, 0, 0);
+        }
+        const int gy = Y0 + (hy - 1) * DWS_FD, gx = X0 + (hx - 1) * DWS_FD;
+        const bool ok = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float4 v = bn_relu4(make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]), s4[mt], t4[mt]);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp < NPX) sA[(mt * 4 + g) * DWS_SA + hp] = v;
+        }
+    }
+}
 
 template <int FIRST>
 __global__ __launch_bounds__(256, 4) void k_ref_dws(const float *__restrict__ in, const float *__restrict__ wf,
@@ -700,39 +754,7 @@ __global__ __launch_bounds__(256, 4) void k_ref_dws(const float *__restrict__ in
         for (int k = 0; k < NLD; ++k)
             if (tid + 256 * k < 3 * WIN) sImg[tid + 256 * k] = iv[k];
         __syncthreads();
-        // the 32 channels of every halo pixel: one accumulator per item, the tap rows walked in an outer loop that is NOT
-        // unrolled, so that only one row of weights (3 kw x 3 ci float4) is live at a time; chain = (kh, kw) ascending, ci inner
-        float4 a[SITER];
-        const float *sp[SITER];
-#pragma unroll
-        for (int i = 0; i < SITER; ++i) {
-            const int hp = (tid >> 3) + 32 * i;
-            const int hy = hp / RH_X, hx = hp - hy * RH_X;
-            sp[i] = sImg + (hp < NPX ? (hy * DWS_FD) * DWS_FC + hx * DWS_FD : 0);
-            a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh) {
-            float4 wq[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) wq[j] = *reinterpret_cast<const float4 *>(wf + (kh * 9 + j) * 32 + c4 * 4);   // [kw][ci]
-#pragma unroll
-            for (int i = 0; i < SITER; ++i)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                    for (int ci = 0; ci < 3; ++ci) fma4s(a[i], sp[i][ci * WIN + kh * DWS_FC + kw], wq[kw * 3 + ci]);
-        }
-#pragma unroll
-        for (int i = 0; i < SITER; ++i) {
-            const int hp = (tid >> 3) + 32 * i;
-            const int hy = hp / RH_X, hx = hp - hy * RH_X;
-            const int gy = t.Y0 + (hy - 1) * DWS_FD, gx = t.X0 + (hx - 1) * DWS_FD;
-            const bool ok = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            float4 v = bn_relu4(a[i], s4, t4);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hp < NPX) sA[c4 * DWS_SA + hp] = v;
-        }
+        first_conv_mfma<3>(sImg, wf, bn_s, bn_t, sA, t.Y0, t.X0, H, W, lane, wave);
         __syncthreads();          // sImg (= sB) is dead from here; sA is complete
     } else if (FIRST == 1) {
         float *sImg = reinterpret_cast<float *>(sB);
@@ -753,9 +775,6 @@ __global__ __launch_bounds__(256, 4) void k_ref_dws(const float *__restrict__ in
             ixs[k] = iok[k] ? gx : 0;
         }
         deferred_at_n<4>(dm, iys, ixs, H, W, iv);       // all loads of the four points in flight together
-        float4 wq[9];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) wq[tap] = *reinterpret_cast<const float4 *>(wf + tap * 32 + c4 * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (tid + 256 * k < DWS_FR * DWS_FC) sImg[tid + 256 * k] = iok[k] ? iv[k] : 0.0f;
@@ -766,26 +785,7 @@ __global__ __launch_bounds__(256, 4) void k_ref_dws(const float *__restrict__ in
             if (gy < H && gx < W)
                 pmat[(int64_t)t.b * H * W + (int64_t)gy * W + gx] = sImg[((ty + 1) * DWS_FD + 1) * DWS_FC + (tx + 1) * DWS_FD + 1];
         }
-        // the 32 channels of every halo pixel, BN + ReLU applied, straight into sA (two iterations per trip: the fully unrolled
-        // loop kept all 54 window reads and 6 results live -- 188 VGPRs, two workgroups per CU instead of four)
-#pragma unroll 2
-        for (int i = 0; i < SITER; ++i) {
-            const int hp = (tid >> 3) + 32 * i;
-            const int hy = hp / RH_X, hx = hp - hy * RH_X;
-            const int gy = t.Y0 + (hy - 1) * DWS_FD, gx = t.X0 + (hx - 1) * DWS_FD;
-            const bool ok = hp < NPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const float *sp = sImg + (hp < NPX ? (hy * DWS_FD) * DWS_FC + hx * DWS_FD : 0);
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    fma4s(a, sp[kh * DWS_FC + kw], wq[kh * 3 + kw]);      // four output channels: two v_pk_fma_f32
-                }
-            float4 v = bn_relu4(a, s4, t4);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hp < NPX) sA[c4 * DWS_SA + hp] = v;
-        }
+        first_conv_mfma<1>(sImg, wf, bn_s, bn_t, sA, t.Y0, t.X0, H, W, lane, wave);
         __syncthreads();          // sImg (= sB) is dead from here; sA is complete
     } else {
         const float *inb = in + (int64_t)t.b * H * W * 32;
@@ -1419,7 +1419,21 @@ int launch_ref_dws(const RefDws &l, const float *in, float *out, int B, int H, i
 // be deferred; refinement1_left: cin = 3)
 bool ref_first_dws_can_fuse(const RefDws &l, int cin) { return (cin == 1 || cin == 3) && l.dil == DWS_FD; }
 
-int launch_ref_first_dws(const RefDws &l, const float *img, int cin, const float *wfirst, float *out, int B, int H, int W,
+// A fragments of the fused first convolution for first_conv_mfma: [mt][j][lane], lane (m, g) -> W[16 mt + m][k = 4 j + g],
+// k = cin * tap + ci (zero beyond 9 cin); w is the Conv2D weight [32][cin][3][3]
+int packed_first_mfma_floats(int cin) { return 2 * ((9 * cin + 3) / 4) * 64; }
+void pack_first_mfma(const float *w, int cin, float *out)
+{
+    const int K = 9 * cin, J = (K + 3) / 4;
+    for (int mt = 0; mt < 2; ++mt)
+        for (int j = 0; j < J; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = lane & 15, g = lane >> 4, k = 4 * j + g, tap = k / cin, ci = k % cin;
+                out[(mt * J + j) * 64 + lane] = k < K ? w[((16 * mt + m) * cin + ci) * 9 + tap] : 0.0f;
+            }
+}
+
+int launch_ref_first_dws(const RefDws &l, const float *img, int cin, const float *wfrag, float *out, int B, int H, int W,
                          hipStream_t st, const float *plow, int ph, int pw, float *pmat, float ioff)
 {
     if (!ref_first_dws_can_fuse(l, cin)) {
@@ -1433,12 +1447,13 @@ int launch_ref_first_dws(const RefDws &l, const float *img, int cin, const float
     const int nbx = cdiv(W, RT_X * l.dil), nby = cdiv(H, RT_Y * l.dil);
     dim3 grid(nbx * nby * l.dil * l.dil * B), block(256);
     const int wt = use_wt_stores((size_t)B * H * W * 128);
+    const float4 *pw4 = reinterpret_cast<const float4 *>(l.pw);
     if (cin == 3)
-        hipLaunchKernelGGL(k_ref_dws<3>, grid, block, 0, st, img, wfirst, l.bn_s, l.bn_t, l.dw, reinterpret_cast<const float4 *>(l.pw),
-                           out, H, W, l.dil, nbx, nby, wt, (const float *)nullptr, 0, 0, (float *)nullptr, ioff);
+        hipLaunchKernelGGL(k_ref_dws<3>, grid, block, 0, st, img, wfrag, l.bn_s, l.bn_t, l.dw, pw4, out, H, W, l.dil, nbx, nby, wt,
+                           (const float *)nullptr, 0, 0, (float *)nullptr, ioff);
     else
-        hipLaunchKernelGGL(k_ref_dws<1>, grid, block, 0, st, img, wfirst, l.bn_s, l.bn_t, l.dw, reinterpret_cast<const float4 *>(l.pw),
-                           out, H, W, l.dil, nbx, nby, wt, plow, ph, pw, pmat, ioff);
+        hipLaunchKernelGGL(k_ref_dws<1>, grid, block, 0, st, img, wfrag, l.bn_s, l.bn_t, l.dw, pw4, out, H, W, l.dil, nbx, nby, wt,
+                           plow, ph, pw, pmat, ioff);
     LWS_LAUNCH_CHECK();
     return LWS_OK;
 }

@@ -107,7 +107,7 @@ def test_options_validate_names_and_ranges(hip_lib):
     rc, h = _create(hip_lib)
     assert rc == 0
     v = ctypes.c_int(123)
-    for name, default in [(b"fuse_first", 1), (b"defer_upsample", 1), (b"side_streams", 1), (b"split_bf16", 0), (b"ref_chunk_mb", 72),
+    for name, default in [(b"fuse_first", 3), (b"defer_upsample", 1), (b"side_streams", 1), (b"split_bf16", 0), (b"ref_chunk_mb", 72),
                           (b"ref_pipe", -1), (b"warp_form", 1), (b"fuse_last1", 1), (b"fork2_after", -1), (b"fuse_ref_last", -1)]:
         assert hip_lib.lws_get_option(h, name, ctypes.byref(v)) == 0 and v.value == default
     assert hip_lib.lws_set_option(h, b"fork2_after", 2) == 0

@@ -252,14 +252,20 @@ def test_refine_bitexact(dev, model, B, H, W, chunk_mb, fuse_last):
     rng = np.random.default_rng(9)
     left = rng.standard_normal((B, 3, H, W)).astype(np.float32)
     pred3 = (rng.random((B, 1, H, W)) * 150.0).astype(np.float32)
+    want = C.refine(left, pred3, model.state_dict())
     model.set_option("ref_chunk_mb", chunk_mb)
     model.set_option("fuse_ref_last", fuse_last)
+    default_ff = model.get_option("fuse_first")
     try:
-        got = ops.refine(model._h, cu(left, dev), cu(pred3, dev))
+        # "fuse_first": which of refinement1's first convolutions (bit 0: disparity branch 1 -> 32, bit 1: left branch 3 -> 32) run
+        # inside their first depthwise block (on fp32 MFMA) -- every combination, the same bits
+        for ff in (3, 0, 1, 2):
+            model.set_option("fuse_first", ff)
+            assert_bits(ops.refine(model._h, cu(left, dev), cu(pred3, dev)), want, f"refine fuse_first={ff}")
     finally:
         model.set_option("ref_chunk_mb", 72)
         model.set_option("fuse_ref_last", -1)
-    assert_bits(got, C.refine(left, pred3, model.state_dict()), "refine")
+        model.set_option("fuse_first", default_ff)
 
 
 def test_refine_ragged_sweep(dev, model):
@@ -350,7 +356,7 @@ def test_forward_repeatable_batch8(dev, model):
             assert torch.equal(one[s], ref[s][3:4])
 
 
-OPTION_PLANS = [{"fuse_first": 0}, {"fuse_first": 3}, {"fuse_first": 2}, {"defer_upsample": 0}, {"ref_chunk_mb": 0}, {"ref_chunk_mb": 1},
+OPTION_PLANS = [{"fuse_first": 0}, {"fuse_first": 1}, {"fuse_first": 2}, {"defer_upsample": 0}, {"ref_chunk_mb": 0}, {"ref_chunk_mb": 1},
                 {"side_streams": 0}, {"side_streams": 0, "fuse_first": 0}, {"warp_form": 0}, {"warp_form": 0, "defer_upsample": 0},
                 {"fuse_last1": 0}, {"fuse_last1": 1, "warp_form": 0}, {"fuse_ref_last": 0}, {"fuse_ref_last": 1},
                 {"fork2_after": 0}, {"fork2_after": 2}, {"fork2_after": 1, "side_streams": 0}, {"ref_pipe": 1, "ref_chunk_mb": 1},
@@ -1170,21 +1176,21 @@ def test_profiler_counts_and_sampling(dev, model, hip_lib):
     # stage 1's soft-argmin inside its last Conv3D layer, and no k_upsample_add launch, unless "fuse_last1" / "defer_upsample" = 0)
     assert got["volume_l1_shift"] in (0, 1) and got["volume_l1_warp"] == 2 and got["ref_conv64"] == 1 and got["ref_dws"] == 11
     assert got["ref_last"] == 1 and got["softargmin"] == 0 and got["upsample_add"] == 0 and got["feature_conv2d"] == 8
-    assert got["ref_first"] == 1
-    assert sum(cnt) == 4 + 8 + 3 + 3 + 2 + 1 + 11 + 1 + 8 + 1        # 42 launches per batch-1 forward (33 on the caller's stream)
+    assert got["ref_first"] == 0                                       # (both first convolutions run inside their first blocks)
+    assert sum(cnt) == 4 + 8 + 3 + 3 + 2 + 11 + 1 + 8 + 1            # 41 launches per batch-1 forward (33 on the caller's stream)
     assert all(t >= 0.0 for t in tot) and tot[names.index("conv3d_mid16")] > 0.0
-    # "fuse_first" bit 1: refinement1_left's 3 -> 32 convolution inside its first block -- one launch less, the same bits
+    # "fuse_first" bit 1 off: refinement1_left's 3 -> 32 convolution as its own launch again -- one launch more, the same bits
     want = [p.clone() for p in model(left, right)]
-    model.set_option("fuse_first", 3)
+    model.set_option("fuse_first", 1)
     try:
         _lib.check(hip_lib.lws_profile_enable(model._h, -1))
-        fused = model(left, right)
+        unfused = model(left, right)
         torch.cuda.synchronize()
         _lib.check(hip_lib.lws_profile_read(model._h, tot, cnt))
-        assert cnt[names.index("ref_first")] == 0 and cnt[names.index("ref_dws")] == 11 and sum(cnt) == 41
-        assert all(torch.equal(a, b) for a, b in zip(fused, want))
+        assert cnt[names.index("ref_first")] == 1 and cnt[names.index("ref_dws")] == 11 and sum(cnt) == 42
+        assert all(torch.equal(a, b) for a, b in zip(unfused, want))
     finally:
-        model.set_option("fuse_first", 1)
+        model.set_option("fuse_first", 3)
     # lws_clock_stamp / lws_clock_read: the shader clock k_conv3d_mid16 ran at, from its own s_memtime / s_memrealtime stamps
     ghz = ctypes.c_double(0.0)
     _lib.check(hip_lib.lws_clock_stamp(model._h, 1))

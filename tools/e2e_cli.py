@@ -66,8 +66,15 @@ def main():
         args = inf.build_parser().parse_args(["--img_path", tmp, "--save_path", os.path.join(tmp, "out_seq"), "--synthetic_weights"])
         dev = torch.device("cuda", 0)
         model = LWSNet(args, device=dev).set_state_dict(make_state_dict(7, args)).eval()
-        print(f"# {a.pairs} pairs 1242x375 -> crop 368x1232, maxdisplist {args.maxdisplist}, host has {os.cpu_count()} logical CPUs, "
-              f"torch {torch.__version__}; seeded synthetic weights")
+        quota = "?"
+        for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            try:
+                quota = f"{f}: {open(f).read().strip()}"
+                break
+            except OSError:
+                pass
+        print(f"# {a.pairs} pairs 1242x375 -> crop 368x1232, maxdisplist {args.maxdisplist}, host has {os.cpu_count()} logical CPUs "
+              f"(affinity {len(os.sched_getaffinity(0))}, cgroup quota {quota}), torch {torch.__version__}; seeded synthetic weights")
         os.makedirs(args.save_path)
         t0 = time.perf_counter()
         inf.inference(model, lefts, rights, args, log)
