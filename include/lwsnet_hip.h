@@ -138,6 +138,15 @@ int lws_refine(lws_handle h, const float *left, const float *pred3, int B, int H
 int lws_forward(lws_handle h, const float *left, const float *right, int B, int H, int W, float *const pred_out[4],
                 void *stream);
 
+/* ---- the per-pixel steps of the I/O harness on either side of forward (ABI v8) ------------- */
+/* inference.py:83-85,102-103: ToTensor + Normalize of the (already cropped) image.  rgb [B,H,W,3] uint8, device memory ->
+ * out [B,3,H,W] float32 = ((v / 255) - mean[c]) / std[c], one IEEE float32 operation each -- bit for bit what numpy computes in
+ * lwsnet_amd/imageio.py:to_input.  mean, std: HOST pointers to 3 floats (the ImageNet constants of dataloader/dataloader.py:10-11). */
+int lws_preprocess_rgb8(const uint8_t *rgb, float *out, int B, int H, int W, const float *mean, const float *std, void *stream);
+/* inference.py:114-115: `.astype(np.uint8)` (C cast: truncation toward zero, wrap-around outside 0..255) + cv2.applyColorMap.
+ * disp [n] float32 -> rgb [n,3] uint8 = lut[(uint8)(int64)disp]; lut: 256 x 3 bytes in device memory (lwsnet_amd.imageio.jet_lut). */
+int lws_apply_lut8(const float *disp, const uint8_t *lut, uint8_t *rgb, int64_t n, void *stream);
+
 /* Launch-plan options of lws_forward / lws_disparity_stages.  They change which kernels / streams carry the work, never
  * the arithmetic: every setting returns the same bits (tests/test_gpu_parity.py::test_forward_schedule_options) -- except
  * the opt-in numerics mode "split_bf16".  (ABI v8 removed the options two rounds of sweeps had retired: left_at, split_heads,

@@ -42,6 +42,8 @@ PROTOTYPES = {
     "lws_feature_extraction": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lws_refine": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lws_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp * 4, _vp]),
+    "lws_preprocess_rgb8": (_i, [_vp, _vp, _i, _i, _i, c_float_p, c_float_p, _vp]),
+    "lws_apply_lut8": (_i, [_vp, _vp, _vp, ctypes.c_int64, _vp]),
     "lws_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
     "lws_get_option": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(_i)]),
     "lws_profile_enable": (_i, [_vp, _i]),

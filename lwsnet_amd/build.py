@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblwsnet_hip.so")
-SOURCES = ["lws_api.hip", "lws_pool.hip", "lws_volume.hip", "lws_regress.hip", "lws_conv3d.hip", "lws_conv2d.hip"]
+SOURCES = ["lws_api.hip", "lws_pool.hip", "lws_volume.hip", "lws_regress.hip", "lws_conv3d.hip", "lws_conv2d.hip", "lws_io.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
 

@@ -117,7 +117,7 @@ static inline int use_wt_stores(size_t out_bytes) { return out_bytes <= ((size_t
 // Diagnostic builds only (LWS_EXTRA_FLAGS="-DLWS_STAMPS=<kernel id>"; tools/stamps.py): every workgroup of the selected
 // kernel stores s_memtime stamps of its phases (slots 0..5) and the s_memrealtime (100 MHz) of its first and latest stamp
 // (slots 6, 7: the in-kernel clock = d s_memtime / d s_memrealtime x 100 MHz) in a per-translation-unit buffer.  The shipped library compiles
-// LWS_STAMPK to nothing.  Kernel ids: 1 mid16, 2 mid8, 3 conv3d_last, 4 conv3d_first, 5 ref_dws, 6 ref_conv64,
+// LWS_STAMPK to nothing.  Kernel ids: 1 mid16, 3 conv3d_last, 4 conv3d_first, 5 ref_dws, 6 ref_conv64,
 // 7 conv2d_nchw, 8 ref_first, 9 ref_last, 10 volume_warp, 11 volume_shift, 12 softargmin_upsample, 13..16 conv2d_pair (dres0, dres1, conv1+2, conv3+4), 18 conv3d_mid8q, 19 conv3d_mid16x, 20 conv3d_mid8x, 21 ref_conv64x.
 #ifdef LWS_STAMPS
 #define LWS_DEFINE_STAMPS(tu)                                                                                      \

@@ -10,10 +10,11 @@ after a device synchronise and excludes the first (warm-up) call; `--vis` is acc
 
 `--workers N` (not in the reference; directory mode only): the reference's loop (inference.py:88-137) is one pair at a time --
 decode, forward, colour-map, encode, all on one thread, which is what its published "10 FPS" measures.  With N > 0 the same
-per-pair work is pipelined: N host worker PROCESSES (spawned, numpy + PIL only, no GPU) decode / crop / normalise into
-shared-memory slots that are registered with HIP as pinned memory, a copy stream uploads them, the forwards run through lws_pool
-(several batch-1 forwards in flight), a second copy stream brings the stage-4 maps back into the slot and the same workers
-colour-map and PNG-encode them.  The files written are byte-identical to the sequential loop's
+per-pair work is pipelined: N host worker PROCESSES (spawned, numpy + PIL only, no GPU) PNG-decode and crop into shared-memory
+slots that are registered with HIP as pinned memory; a copy stream uploads the uint8 pixels and normalises them on the device
+(lws_preprocess_rgb8: bit for bit the host transform), the forwards run through lws_pool (several batch-1 forwards in flight), a
+second stream casts and colour-maps the stage-4 map on the device (lws_apply_lut8) and brings 3 bytes per pixel back into the
+slot, and the same workers PNG-encode them.  The files written are byte-identical to the sequential loop's
 (tests/test_gpu_parity.py::test_cli_directory_pipeline_writes_identical_files); the end-to-end rate and where the time goes
 are logged and returned (profiles/r06/e2e_cli.txt).
 """
@@ -55,21 +56,22 @@ def build_parser():
 
 def _host_worker(task_q, done_q, slot_names, H, W):
     """Body of a host worker PROCESS of the pipelined directory mode (spawned: a fresh interpreter that imports numpy and PIL
-    only and never touches the GPU).  Tasks: ("decode", i, slot, left path, right path) -> decode, crop, normalise both images
-    into the slot's shared memory (inference.py:90-103); ("encode", i, slot, out path) -> uint8 cast, JET, PNG of the slot's
-    stage-4 map (inference.py:114-115,136).  Python threads do this work at most ~16-wide (the interpreter lock); processes
-    scale with the host's cores."""
+    only and never touches the GPU).  Tasks: ("decode", i, slot, left path, right path) -> PNG decode + crop of both images into
+    the slot's shared memory as uint8 RGB (inference.py:90-100; the normalisation of :102-103 runs on the GPU,
+    lws_preprocess_rgb8); ("encode", i, slot, out path) -> PNG of the slot's colour-mapped stage-4 map (inference.py:136; the
+    uint8 cast and the JET table of :114-115 run on the GPU, lws_apply_lut8).  Python threads do this work at most ~16-wide (the
+    interpreter lock); processes scale with the host's cores."""
     from multiprocessing import shared_memory
 
     from lwsnet_amd import imageio as io
-    n_in = 3 * H * W
+    n_px = H * W * 3
     shms = {}
 
     def views(sid):
         if sid not in shms:
             shm = shared_memory.SharedMemory(name=slot_names[sid])
-            buf = np.ndarray((2 * n_in + H * W,), np.float32, buffer=shm.buf)
-            shms[sid] = (shm, buf[:n_in].reshape(3, H, W), buf[n_in:2 * n_in].reshape(3, H, W), buf[2 * n_in:].reshape(H, W))
+            buf = np.ndarray((3 * n_px,), np.uint8, buffer=shm.buf)
+            shms[sid] = (shm, buf[:n_px].reshape(H, W, 3), buf[n_px:2 * n_px].reshape(H, W, 3), buf[2 * n_px:].reshape(H, W, 3))
         return shms[sid]
 
     while True:
@@ -86,11 +88,11 @@ def _host_worker(task_q, done_q, slot_names, H, W):
                     done_q.put(("skipped", i, sid, 0.0))
                     continue
                 _, vl, vr, _ = views(sid)
-                np.copyto(vl, io.to_input(left))
-                np.copyto(vr, io.to_input(right))
+                np.copyto(vl, left)
+                np.copyto(vr, right)
                 done_q.put(("decoded", i, sid, time.perf_counter() - t0))
             else:
-                io.save_png(task[3], io.disparity_to_color(views(sid)[3]))
+                io.save_png(task[3], views(sid)[3])
                 done_q.put(("encoded", i, sid, time.perf_counter() - t0))
         except Exception as e:                                          # noqa: BLE001 (reported to the parent, which raises)
             done_q.put(("error", i, sid, f"{kind} of pair {i}: {type(e).__name__}: {e}"))
@@ -99,38 +101,38 @@ def _host_worker(task_q, done_q, slot_names, H, W):
 
 
 class _Slot:
-    """Buffers of one pair in flight: a shared-memory block [left | right | stage-4 map] the host workers read and write,
-    registered with HIP as pinned memory when the runtime allows (otherwise staged through pinned tensors), device inputs and
-    the four device stage maps."""
+    """Buffers of one pair in flight: a shared-memory block [left RGB | right RGB | colour-mapped stage-4 map], all uint8 HWC,
+    that the host workers write and read -- registered with HIP as pinned memory when the runtime allows (otherwise staged
+    through pinned tensors) --, the device copies of the three images, the normalised device inputs and the four stage maps."""
 
     def __init__(self, dev, H, W):
         from multiprocessing import shared_memory
 
         import torch
-        n_in = 3 * H * W
-        self.shm = shared_memory.SharedMemory(create=True, size=4 * (2 * n_in + H * W))
-        host = torch.frombuffer(self.shm.buf, dtype=torch.float32)
+        n_px = H * W * 3
+        self.shm = shared_memory.SharedMemory(create=True, size=3 * n_px)
+        host = torch.frombuffer(self.shm.buf, dtype=torch.uint8)
         self.registered = False
         try:
-            rc = torch.cuda.cudart().cudaHostRegister(host.data_ptr(), host.numel() * 4, 0)
-            self.registered = (rc == 0 or int(rc) == 0) and host.is_pinned()
+            rc = torch.cuda.cudart().cudaHostRegister(host.data_ptr(), host.numel(), 0)
+            self.registered = int(rc) == 0 and host.is_pinned()
         except Exception:                                               # noqa: BLE001 (fall back to staging copies)
             self.registered = False
-        self.host_l, self.host_r, self.host_out = host[:n_in].view(1, 3, H, W), host[n_in:2 * n_in].view(1, 3, H, W), host[2 * n_in:].view(H, W)
+        self.host_in, self.host_out = host[:2 * n_px].view(2, H, W, 3), host[2 * n_px:].view(H, W, 3)
         if not self.registered:
-            self.pin_l = torch.empty((1, 3, H, W), dtype=torch.float32).pin_memory()
-            self.pin_r = torch.empty((1, 3, H, W), dtype=torch.float32).pin_memory()
-            self.pin_out = torch.empty((H, W), dtype=torch.float32).pin_memory()
-        self.dev_l = torch.empty((1, 3, H, W), dtype=torch.float32, device=dev)
-        self.dev_r = torch.empty((1, 3, H, W), dtype=torch.float32, device=dev)
+            self.pin_in = torch.empty((2, H, W, 3), dtype=torch.uint8).pin_memory()
+            self.pin_out = torch.empty((H, W, 3), dtype=torch.uint8).pin_memory()
+        self.dev_in = torch.empty((2, H, W, 3), dtype=torch.uint8, device=dev)
+        self.dev_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        self.dev_lr = torch.empty((2, 3, H, W), dtype=torch.float32, device=dev)      # [left | right], normalised
         self.outs = [torch.empty((1, 1, H, W), dtype=torch.float32, device=dev) for _ in range(4)]
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]      # h2d begin / end, d2h begin / end
         self.t0 = 0.0
 
     def close(self):
         import torch
-        ptr = self.host_l.data_ptr()
-        self.host_l = self.host_r = self.host_out = None
+        ptr = self.host_in.data_ptr()
+        self.host_in = self.host_out = None
         if self.registered:
             try:
                 torch.cuda.cudart().cudaHostUnregister(ptr)
@@ -151,12 +153,14 @@ def inference_pipelined(model, left_imgs, right_imgs, args, log):
 
     import torch
     from . import imageio as io
+    from . import ops
     dev = model.device
     N, P = max(1, int(args.workers)), max(1, int(args.gpu_workers))
     H, W = io.CROP_H, io.CROP_W
     total = len(left_imgs)
     torch.cuda.set_device(dev)
     slots = [_Slot(dev, H, W) for _ in range(2 * P + 2 * N)]
+    lut_dev = torch.from_numpy(io.jet_lut()).to(dev)
     ctx = mp.get_context("spawn")                        # fresh interpreters: a forked child of a process that holds HIP state is not safe
     task_q, done_q = ctx.Queue(), ctx.Queue()
     names = [sl.shm.name for sl in slots]
@@ -171,7 +175,6 @@ def inference_pipelined(model, left_imgs, right_imgs, args, log):
     acc = {"decode_s": 0.0, "encode_s": 0.0, "h2d_ms": 0.0, "d2h_ms": 0.0, "pairs": 0, "skipped": 0, "latency_s": 0.0}
     errors = []
     h2d, d2h = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-    finished = threading.Event()
 
     def feeder():
         for i in range(total):
@@ -192,7 +195,8 @@ def inference_pipelined(model, left_imgs, right_imgs, args, log):
                 dst = sl.host_out if sl.registered else sl.pin_out
                 with torch.cuda.stream(d2h):
                     sl.ev[2].record()
-                    dst.copy_(sl.outs[3][0, 0], non_blocking=True)      # directory mode keeps the stage-4 map only (:133-137)
+                    ops.apply_lut8(sl.outs[3][0, 0], lut_dev, out=sl.dev_rgb)   # inference.py:114-115; directory mode keeps stage 4 (:133-137)
+                    dst.copy_(sl.dev_rgb, non_blocking=True)
                     sl.ev[3].record()
                 sl.ev[3].synchronize()
                 if not sl.registered:
@@ -202,11 +206,12 @@ def inference_pipelined(model, left_imgs, right_imgs, args, log):
                 errors.append(e)
                 done_q.put(("error", i, sid, repr(e)))
 
+    wall = 0.0
     try:
         # warm-up outside the clock (the reference times its first call; this build never does): library, pool and workers up
         with model.pool(workers=P) as gpool:
             gpool.reserve(1, H, W)
-            gpool.submit(slots[0].dev_l.zero_(), slots[0].dev_r.zero_(), out=slots[0].outs).result()
+            gpool.submit(slots[0].dev_lr[:1].zero_(), slots[0].dev_lr[1:].zero_(), out=slots[0].outs).result()
             torch.cuda.synchronize(dev)
             t_begin = time.perf_counter()
             tf = threading.Thread(target=feeder, daemon=True)
@@ -224,16 +229,15 @@ def inference_pipelined(model, left_imgs, right_imgs, args, log):
                 sl = slots[sid]
                 if kind == "decoded":
                     acc["decode_s"] += val
-                    src_l, src_r = (sl.host_l, sl.host_r) if sl.registered else (sl.pin_l, sl.pin_r)
+                    src = sl.host_in if sl.registered else sl.pin_in
                     if not sl.registered:
-                        sl.pin_l.copy_(sl.host_l)
-                        sl.pin_r.copy_(sl.host_r)
+                        sl.pin_in.copy_(sl.host_in)
                     with torch.cuda.stream(h2d):
                         sl.ev[0].record()
-                        sl.dev_l.copy_(src_l, non_blocking=True)
-                        sl.dev_r.copy_(src_r, non_blocking=True)
+                        sl.dev_in.copy_(src, non_blocking=True)
+                        ops.preprocess_rgb8(sl.dev_in, out=sl.dev_lr)           # inference.py:102-103 (ToTensor + Normalize)
                         sl.ev[1].record()
-                        job = gpool.submit(sl.dev_l, sl.dev_r, out=sl.outs)     # starts behind the copies (after_stream = h2d)
+                        job = gpool.submit(sl.dev_lr[:1], sl.dev_lr[1:], out=sl.outs)   # starts behind them (after_stream = h2d)
                     inflight.put((i, sid, job))
                 elif kind == "encoded":
                     acc["encode_s"] += val
@@ -252,7 +256,6 @@ def inference_pipelined(model, left_imgs, right_imgs, args, log):
                     errors.append(RuntimeError(val))
             wall = time.perf_counter() - t_begin
             inflight.put(None)
-            finished.set()
             tc.join(timeout=30.0)
     finally:
         for _ in procs:

@@ -182,3 +182,38 @@ def forward(handle, left, right, out=None):
         _lib.check(lib.lws_forward(handle, _ptr(l), _ptr(r), B, H, W, arr(*[t.data_ptr() for t in preds]), _stream()),
                    "lws_forward")
     return preds
+
+
+def preprocess_rgb8(rgb_u8, out=None):
+    """ToTensor + Normalize(imagenet) of inference.py:83-85,102-103 on the device: rgb_u8 [B,H,W,3] uint8 -> [B,3,H,W] float32,
+    bit for bit lwsnet_amd.imageio.to_input (numpy)."""
+    from .synth import IMAGENET_MEAN, IMAGENET_STD
+    if not isinstance(rgb_u8, torch.Tensor) or not rgb_u8.is_cuda or rgb_u8.dtype != torch.uint8 or rgb_u8.dim() != 4 or rgb_u8.shape[3] != 3:
+        raise ValueError("rgb_u8 must be a [B,H,W,3] uint8 tensor on a HIP device")
+    rgb_u8 = rgb_u8.contiguous()
+    B, H, W, _ = rgb_u8.shape
+    if out is None:
+        out = torch.empty((B, 3, H, W), device=rgb_u8.device, dtype=torch.float32)
+    elif tuple(out.shape) != (B, 3, H, W) or out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous():
+        raise ValueError("out must be a contiguous [B,3,H,W] float32 device tensor")
+    mean = (ctypes.c_float * 3)(*[float(v) for v in IMAGENET_MEAN])
+    std = (ctypes.c_float * 3)(*[float(v) for v in IMAGENET_STD])
+    with torch.cuda.device(rgb_u8.device):
+        _lib.check(_lib.load().lws_preprocess_rgb8(_ptr(rgb_u8), _ptr(out), B, H, W, mean, std, _stream()), "lws_preprocess_rgb8")
+    return out
+
+
+def apply_lut8(disp, lut_dev, out=None):
+    """`.astype(np.uint8)` + colour map of inference.py:114-115 on the device: disp (any shape) float32 -> [...,3] uint8 through
+    lut_dev ([256,3] uint8 on the device), bit for bit lwsnet_amd.imageio.disparity_to_color."""
+    d = _dev(disp, "disp")
+    if not isinstance(lut_dev, torch.Tensor) or not lut_dev.is_cuda or lut_dev.dtype != torch.uint8 or lut_dev.numel() != 768:
+        raise ValueError("lut_dev must be a [256,3] uint8 tensor on a HIP device")
+    if out is None:
+        out = torch.empty(tuple(d.shape) + (3,), device=d.device, dtype=torch.uint8)
+    elif out.numel() != 3 * d.numel() or out.dtype != torch.uint8 or not out.is_cuda or not out.is_contiguous():
+        raise ValueError("out must be a contiguous uint8 device tensor with 3 bytes per disparity value")
+    with torch.cuda.device(d.device):
+        _lib.check(_lib.load().lws_apply_lut8(_ptr(d), _ptr(lut_dev.contiguous()), _ptr(out), ctypes.c_int64(d.numel()), _stream()),
+                   "lws_apply_lut8")
+    return out

@@ -1247,3 +1247,26 @@ def test_cli_directory_pipeline_writes_identical_files(dev, hip_lib, tmp_path):
         assert got == seq, f"--workers {w}: files differ from the sequential loop"
         st = inf.main.last_stats
         assert st["pairs"] == 12 and st["skipped"] == 1 and st["pairs_per_s"] > 0
+
+
+def test_io_kernels_match_the_host_pipeline(dev, hip_lib):
+    """lws_preprocess_rgb8 / lws_apply_lut8 (include/lwsnet_hip.h): the input transform of /root/reference/inference.py:83-85,
+    102-103 and the output mapping of :114-115 as device kernels, bit for bit what numpy computes in lwsnet_amd/imageio.py --
+    every byte value in every channel, and disparities that are negative, fractional, beyond 255 (the C cast wraps), huge, NaN."""
+    from lwsnet_amd import imageio, ops
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, size=(2, 37, 53, 3), dtype=np.uint8)
+    img[0, :, :, :].reshape(-1)[:768] = np.repeat(np.arange(256, dtype=np.uint8), 3)          # all 256 values in all three channels
+    got = ops.preprocess_rgb8(torch.from_numpy(img).to(dev)).cpu().numpy()
+    want = np.stack([imageio.to_input(img[b]) for b in range(2)])
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    disp = (rng.random((61, 47)) * 300.0 - 20.0).astype(np.float32)
+    disp[0, :8] = [0.0, -0.5, -1.0, 255.999, 256.0, 1e10, -3e9, 191.5]
+    disp[1, :3] = [np.nan, np.inf, -np.inf]
+    lut = torch.from_numpy(imageio.jet_lut()).to(dev)
+    with np.errstate(invalid="ignore"):
+        want_rgb = imageio.disparity_to_color(disp)
+    got_rgb = ops.apply_lut8(torch.from_numpy(disp).to(dev), lut).cpu().numpy()
+    assert got_rgb.shape == (61, 47, 3) and np.array_equal(got_rgb, want_rgb)
+    with pytest.raises(ValueError):
+        ops.preprocess_rgb8(torch.zeros((1, 3, 8, 8), dtype=torch.uint8, device=dev))

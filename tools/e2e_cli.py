@@ -104,8 +104,9 @@ def main():
                   f"{st['encode_ms_per_pair']:9.2f} {st['h2d_ms_per_pair']:6.3f} {st['d2h_ms_per_pair']:6.3f} {st['latency_ms_per_pair']:10.1f} {str(st['shared_memory_pinned']):>10s} "
                   f"{n == nseq and d == dseq}")
             shutil.rmtree(args.save_path)
-        print("# workers = host worker processes; decode / encode: their time per pair (PIL decode + crop + normalise; uint8 cast + JET + PNG encode); h2d / d2h: "
-              "hipEvent-timed copies per pair (2 x 5.4 MB up, 1.8 MB down); latency: decode start -> file on disk")
+        print("# workers = host worker processes; decode / encode: their time per pair (PNG decode + crop of two images; PNG encode of one); "
+              "h2d: upload of 2 x 1.36 MB uint8 + lws_preprocess_rgb8, d2h: lws_apply_lut8 + download of 1.36 MB (hipEvent-timed); "
+              "latency: decode start -> file on disk")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Produces everything profiles/rNN is built from, on the GPU box, under gpurun_out/final (summaries only: the raw rocprofv3
 # CSVs are condensed on the box by tools/pmc_summary.py / tools/timeline.py and deleted -- gpurun merges back <= 64 MiB):
-#   gpurun --timeout 2400 -- 'bash tools/profile_run.sh'      then here:  python tools/collect_profiles.py gpurun_out/final profiles/r05
+#   gpurun --timeout 2400 -- 'bash tools/profile_run.sh'      then here:  python tools/collect_profiles.py gpurun_out/final profiles/r06
 # Counter passes (--pmc) are separate rocprofv3 runs without any trace domain; the program after `--` is python3 itself.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
@@ -13,8 +13,9 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_b1_driver_flags.json"
 python bench.py --batch 8 --no-cpu-baseline --no-pipelined --steps 30 > "$O/bench_b8.json" 2> /dev/null
 python bench.py --batch 8 --size 368x1232 --no-cpu-baseline --no-pipelined --steps 10 --warmup 3 > "$O/bench_cfg3.json" 2> /dev/null
 python bench.py --size 544x960 --maxdisp0 32 --feature-fp16 --no-cpu-baseline --no-pipelined --steps 20 > "$O/bench_cfg5.json" 2> /dev/null
-# the N-rank code path with two processes on this one GPU (gloo; value is null: the ranks share the chip)
-python bench.py --gpus 2 --one-gpu --batch 8 --steps 10 --warmup 3 --no-cpu-baseline > "$O/bench_two_ranks_one_gpu_b8.json" 2> /dev/null
+# the N-rank code path with two processes on this one GPU (gloo; value is null: the ranks share the chip): both legs -- 1 pair per
+# GPU per step, and config 4's 8 pairs per GPU per step
+python bench.py --gpus 2 --one-gpu --steps 10 --warmup 3 --no-cpu-baseline > "$O/bench_two_ranks_one_gpu.json" 2> /dev/null
 for i in 1 2 3 4 5 6 7 8; do
   python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pipelined 2>/dev/null | python -c "
 import json,sys
@@ -61,7 +62,8 @@ python tools/rbench.py --batch 8 --iters 20 > "$O/rbench_b8.txt" 2> /dev/null
 python tools/rbench.py --batch 8 --size 368x1232 --iters 6 > "$O/rbench_b8_368x1232.txt" 2> /dev/null
 for cfg in "--batch 1" "--batch 8" "--batch 8 --size 368x1232"; do python tools/wbench.py $cfg >> "$O/wbench.txt" 2> /dev/null; done
 GPU_MAX_HW_QUEUES=8 python tools/pool_bench.py --workers 2,3,4,6 > "$O/pool_bench_q8.txt" 2> /dev/null
-python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 100 --warmup 10 --no-cpu-baseline > "$O/bench_torchrun_world1_b1.json" 2> /dev/null
+python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 100 --warmup 10 --no-cpu-baseline --config4 > "$O/bench_torchrun_world1_b1.json" 2> /dev/null
+LWS_BENCH_INJECT=init-fail:0 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29535 bench.py --gpus 1 --steps 100 --warmup 10 --no-cpu-baseline --config4 > "$O/bench_torchrun_world1_fallback_gloo_host.json" 2> /dev/null
 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --batch 8 --steps 40 --warmup 5 --no-cpu-baseline > "$O/bench_torchrun_world1_b8.json" 2> /dev/null
 # in-kernel clock and phase stamps (stamped diagnostic builds; each rebuilds the library)
 for k in "mid16 1" "mid16 8" "mid8q3 1" "mid8q3 8" "conv64 1" "conv64 8" "dws 8" "warp3 8"; do
@@ -70,6 +72,6 @@ for k in "mid16 1" "mid16 8" "mid8q3 1" "mid8q3 8" "conv64 1" "conv64 8" "dws 8"
 done
 python -m lwsnet_amd.build --force > /dev/null 2>&1
 # the opt-in numerics mode as whole steps (never the headline)
-python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pipelined --opt split_bf16=1 > "$O/bench_b1_split_bf16.json" 2> /dev/null
-python bench.py --batch 8 --steps 30 --warmup 5 --no-cpu-baseline --no-pipelined --opt split_bf16=1 > "$O/bench_b8_split_bf16.json" 2> /dev/null
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pipelined --opt split_bf16=7 > "$O/bench_b1_split_bf16.json" 2> /dev/null
+python bench.py --batch 8 --steps 30 --warmup 5 --no-cpu-baseline --no-pipelined --opt split_bf16=7 > "$O/bench_b8_split_bf16.json" 2> /dev/null
 tail -c 300 "$O/bench_b1.json"; echo; tail -2 "$O/smoke.log"; cat "$O/bench_repeats.txt"; du -sh "$O"

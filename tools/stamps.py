@@ -1,7 +1,7 @@
 """Diagnostic: per-workgroup phase stamps (s_memtime, shader cycles) of one kernel.
 
     python tools/stamps.py <kernel> [batch]     # rebuilds the library with -DLWS_STAMPS=<id>, runs, prints medians
-kernels: mid16 mid16x mid8_2 mid8_3 mid8q2 mid8q3 mid8x2 mid8x3 conv64x last1 last3 first1 first3 dws conv64 feat pair0..pair3 ref_last warp2 warp3
+kernels: mid16 mid16x mid8q2 mid8q3 mid8x2 mid8x3 conv64x last1 last3 first1 first3 dws conv64 feat pair0..pair3 ref_last warp2 warp3
 Slots: 0..3 = phase boundaries as placed in the kernel source (LWS_STAMPK); 5 = hardware id of the CU (HW_ID | XCC_ID << 32);
 6, 7 = s_memrealtime at the first / latest stamp.
 CAUTION: a stamped build is a different kernel.  The inline asm can change its register allocation (k_ref_last: 129 registers in
@@ -11,7 +11,7 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 KERNELS = {  # name: (stamp id, translation unit, driver, arg)
-    "mid16": (1, "conv3d", "stack", 0), "mid8_2": (2, "conv3d", "stack", 1), "mid8_3": (2, "conv3d", "stack", 2),
+    "mid16": (1, "conv3d", "stack", 0),
     "last1": (3, "conv3d", "stack", 0), "last3": (3, "conv3d", "stack", 2),
     "first1": (4, "conv3d", "stack", 0), "first3": (4, "conv3d", "stack", 2),
     
