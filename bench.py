@@ -439,7 +439,7 @@ def worker(args):
     # inside k_conv3d_mid16): 16 more forwards right after the timed region -- same queue depth, same mix of kernels -- stamped;
     # the last stage-1 launch of the last forward is read
     clock_ghz = None
-    if c3_first != 8:
+    if c3_first != 8 and not (model.get_option("split_bf16") & 1):      # (k_conv3d_mid16x, the split-bf16 form, carries no stamps)
         ghz = ctypes.c_double(0.0)
         _lib.check(lib.lws_clock_stamp(model._h, 1), "lws_clock_stamp")
         for _ in range(16):

@@ -1327,6 +1327,7 @@ int lws_refine(lws_handle h, const float *left, const float *pred3, int B, int H
     const WsLayout L = ws_layout(h, B, H, W);
     int rc = ensure_ws(h, L.total_all);
     if (rc) return rc;
+    (void)stop_event_take();
     rc = refine_left(h, left, B, H, W, L, (hipStream_t)stream);
     if (rc) return rc;
     return refine_rest(h, const_cast<float *>(pred3), B, H, W, L, pred4, (hipStream_t)stream);   // not written without a DeferState
