@@ -1489,12 +1489,6 @@ static int last_launch(const Stage3d &s, const float *act, const float *skip, fl
 int launch_conv3d_last(const Stage3d &s, const float *act_in, const float *cost_skip, float *cost_out, int B,
                        int D, int h, int w, hipStream_t st)
 {
-    // EXPERIMENT (round 6, removed after the A/B): LWS_LAST_TILE picks another tile shape for the C3 = 32 layer
-    static const int exp_tile = getenv("LWS_LAST_TILE") ? atoi(getenv("LWS_LAST_TILE")) : 0;
-    if (s.c3 == 32 && exp_tile == 1) return last_launch<32, 6, 4, 16, false>(s, act_in, cost_skip, cost_out, nullptr, 0.f, B, D, h, w, st);
-    if (s.c3 == 32 && exp_tile == 2) return last_launch<32, 3, 8, 16, false>(s, act_in, cost_skip, cost_out, nullptr, 0.f, B, D, h, w, st);
-    if (s.c3 == 32 && exp_tile == 3) return last_launch<32, 3, 4, 32, false>(s, act_in, cost_skip, cost_out, nullptr, 0.f, B, D, h, w, st);
-    if (s.c3 == 32 && exp_tile == 4) return last_launch<32, 2, 4, 16, false>(s, act_in, cost_skip, cost_out, nullptr, 0.f, B, D, h, w, st);
     switch (s.c3) {
         case 8: return last_launch<8, 3, 4, 16, false>(s, act_in, cost_skip, cost_out, nullptr, 0.f, B, D, h, w, st);
         case 16: return last_launch<16, 3, 4, 16, false>(s, act_in, cost_skip, cost_out, nullptr, 0.f, B, D, h, w, st);
@@ -1514,10 +1508,6 @@ bool conv3d_last_can_fuse(const Stage3d &s, int D)
 int launch_conv3d_last_softargmin(const Stage3d &s, const float *act_in, const float *cost_skip, float *cost_out,
                                   float *low, float start, int B, int D, int h, int w, hipStream_t st)
 {
-    static const int exp_tile8 = getenv("LWS_LAST8_TILE") ? atoi(getenv("LWS_LAST8_TILE")) : 0;      // EXPERIMENT (round 6)
-    if (D == 9 && s.c3 == 8 && exp_tile8 == 1) return last_launch<8, 9, 4, 16, true>(s, act_in, cost_skip, cost_out, low, start, B, D, h, w, st);
-    if (D == 9 && s.c3 == 8 && exp_tile8 == 2) return last_launch<8, 9, 2, 32, true>(s, act_in, cost_skip, cost_out, low, start, B, D, h, w, st);
-    if (D == 9 && s.c3 == 8 && exp_tile8 == 3) return last_launch<8, 9, 3, 32, true>(s, act_in, cost_skip, cost_out, low, start, B, D, h, w, st);
     if (D == 9 && s.c3 == 8) return last_launch<8, 9, 2, 16, true>(s, act_in, cost_skip, cost_out, low, start, B, D, h, w, st);
     if (D == 9 && s.c3 == 16) return last_launch<16, 9, 2, 16, true>(s, act_in, cost_skip, cost_out, low, start, B, D, h, w, st);
     if (D == 24 && s.c3 == 32) return last_launch<32, 24, 2, 4, true>(s, act_in, cost_skip, cost_out, low, start, B, D, h, w, st);
