@@ -203,7 +203,7 @@ typedef enum {
     LWS_KC_SOFTARGMIN = 6,     /* k_softargmin                           */
     LWS_KC_UPSAMPLE = 7,       /* k_upsample_add                         */
     LWS_KC_FEATURE2D = 8,      /* k_conv2d_nchw (feature extractor)      */
-    LWS_KC_REF_FIRST = 9,      /* k_ref_first                            */
+    LWS_KC_REF_FIRST = 9,      /* k_ref_first (only with option "fuse_first" < 3) */
     LWS_KC_REF_DWS = 10,       /* k_ref_dws                              */
     LWS_KC_REF_CONV64 = 11,    /* k_ref_conv64                           */
     LWS_KC_REF_LAST = 12,      /* k_ref_last                             */
