@@ -10,7 +10,9 @@ returning the stage-4 disparity; for N > 1 every rank runs its own pairs (weak s
 collective) and the stage-4 maps are gathered on rank 0 with ONE RCCL gather per step.
 Rank 0 prints one JSON line.  `roofline` describes the dominant kernel (stage-1 Conv3D 32->32 on fp32
 MFMA): algorithmic FLOPs per launch / average launch duration from hipEvents recorded by the library on
-the launch stream inside the timed region.  `cpu_baseline` is the literal oracle (torch-CPU ops) timed on
+the launch stream inside the timed region; `roofline.traffic` = 2 x FETCH_SIZE + WRITE_SIZE of that kernel from two `rocprofv3
+--pmc` child passes of the same workload that a plain single-GPU run starts before it touches the GPU (separate passes, no trace
+domain; the committed summary under profiles/ is reported when the profiler is not available).  `cpu_baseline` is the literal oracle (torch-CPU ops) timed on
 the host cores of the same box, N = 1 only; it also carries the numerics account: per-stage max-abs distance of the GPU
 result and of the float32 literal oracle to the float64 literal oracle, for the smooth pair and for a white-noise pair.
 
@@ -95,6 +97,61 @@ def _with_traffic(roof, B, H, W, maxdisp0, fp16):
     except Exception as e:                                   # a malformed summary must not break the bench line
         roof["traffic_note"] = f"null: {type(e).__name__} reading the PMC summary"
     return roof
+
+
+def _measure_traffic(args):
+    """roofline.traffic measured IN THIS RUN: two `rocprofv3 --pmc` passes -- FETCH_SIZE and WRITE_SIZE, separate
+    passes, no trace domain, exactly as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- of a 3-step run of this same workload,
+    as child processes of this one, started BEFORE this process touches the GPU (the program after `--` is python3 itself; the
+    child returns right after its timed steps).  Returns ({"traffic": bytes per k_conv3d_mid16 launch, 2 x FETCH + WRITE, ...}, None)
+    or (None, reason); a missing profiler, a refusal, a timeout or an unreadable CSV only cost the in-run number: bench.py then
+    falls back to the committed summary of the same workload (_with_traffic)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(rocprof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="lws_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--steps", "3", "--warmup", "2", "--spinup", "0",
+             "--batch", str(args.batch), "--size", args.size, "--maxdisp0", str(args.maxdisp0), "--no-cpu-baseline", "--no-pipelined",
+             "--no-measure-traffic"] + (["--feature-fp16"] if args.feature_fp16 else []) + [x for o in args.opt for x in ("--opt", o)]
+    kb = {}
+    t0 = time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "run", "--"] + child
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=args.traffic_timeout)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)               # (the exact group started above)
+                except ProcessLookupError:
+                    pass
+                return None, f"the {ctr} pass did not finish within {args.traffic_timeout:.0f} s"
+            if rc != 0:
+                return None, f"rocprofv3 --pmc {ctr} exited with status {rc}"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"the {ctr} pass left no counter_collection.csv"
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                    if "k_conv3d_mid16" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            if not vals:
+                return None, f"no k_conv3d_mid16 rows in the {ctr} pass"
+            kb[ctr] = (sum(vals) / len(vals), len(vals))
+    except Exception as e:                                              # noqa: BLE001 (the bench line must not depend on the profiler)
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"traffic": round((2.0 * kb["FETCH_SIZE"][0] + kb["WRITE_SIZE"][0]) * 1024.0),
+            "FETCH_SIZE_KB_avg": round(kb["FETCH_SIZE"][0], 2), "WRITE_SIZE_KB_avg": round(kb["WRITE_SIZE"][0], 2),
+            "launches_counted": kb["FETCH_SIZE"][1], "seconds": round(time.perf_counter() - t0, 1)}, None
 
 
 def _inject(point, rank):
@@ -222,6 +279,11 @@ def parse_args(argv=None):
     ap.add_argument("--config4", action="store_true",
                     help="also time BASELINE config 4's per-rank shape (8 pairs per GPU per step) and report it under `config4`; "
                          "on by itself for N > 1")
+    ap.add_argument("--no-measure-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic in this run (single-GPU runs only); "
+                         "the committed PMC summary of the same workload is reported instead")
+    ap.add_argument("--traffic-timeout", type=float, default=150.0, help="seconds one rocprofv3 --pmc child pass may take")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)      # the child of _measure_traffic: timed steps only
     ap.add_argument("--config4-steps", type=int, default=None, help="timed steps of the config-4 leg (default: 10..50 following --steps)")
     return ap.parse_args(argv)
 
@@ -240,6 +302,9 @@ def main():
         # plain single-GPU run, in this process: an in-process deadline instead of a supervisor
         launch.arm_watchdog(args.job_timeout, lambda: print(launch.error_line(
             1, args.steps, args.warmup, f"the run did not finish within --job-timeout {args.job_timeout:.0f} s"), flush=True))
+        profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)      # (this process itself runs under rocprofv3)
+        if not (args.no_measure_traffic or args.traffic_child or args.dry_run_cpu or profiled):
+            args.traffic_in_run = _measure_traffic(args)            # children first: this process has not touched the GPU yet
     try:
         return worker(args)
     except (Exception, SystemExit) as e:
@@ -433,6 +498,8 @@ def worker(args):
 
     B = args.batch
     leg = run_leg(B, args.steps, args.warmup, spinup_s=max(0.0, args.spinup), before_timed=arm_profiler, after_timed=read_profiler)
+    if args.traffic_child:
+        return                               # (under rocprofv3 --pmc: the counters of the launches above are all that is wanted)
     elapsed, pred, left, right, left_np, right_np = leg["elapsed"], leg["pred"], leg["left"], leg["right"], leg["left_np"], leg["right_np"]
     G, spun_s, gather_ok, all_ok = leg["G"], leg["spun_s"], leg["gather_ok"], leg["all_ok"]
     # the clock the dominant kernel held on this box / on every rank's GPU (lws_clock_stamp: s_memtime against s_memrealtime
@@ -776,10 +843,21 @@ def worker(args):
         # experiments only (--opt): the opt-in numerics mode, float32-level accuracy but not the oracle's bits
         dtype_name += " with split-bf16 MFMA operands (3 x bf16 per f32, f32 accumulate; not bit-exact against the oracle)"
     roof = _with_traffic(roof, B, H, W, args.maxdisp0, args.feature_fp16)
+    measured, why_not = getattr(args, "traffic_in_run", (None, "not attempted (--no-measure-traffic, or not a plain single-GPU run)"))
+    if roof is not None and measured is not None:
+        # counters read in this run (two rocprofv3 --pmc child passes before the timed run); the committed summary stays beside it
+        roof["traffic_committed"] = roof.get("traffic")
+        roof["traffic"] = measured["traffic"]
+        roof["traffic_source"] = ("this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of the same workload (3 steps, "
+                                  f"{measured['launches_counted']} launches of the kernel each), 2 x FETCH + WRITE; {measured['seconds']} s")
+        roof["traffic_counters_kb"] = {"FETCH_SIZE": measured["FETCH_SIZE_KB_avg"], "WRITE_SIZE": measured["WRITE_SIZE_KB_avg"]}
+        roof.pop("traffic_note", None)
+    elif roof is not None:
+        roof["traffic_in_run_note"] = why_not
     if roof is not None:
-        # `traffic` comes from a committed rocprofv3 --pmc summary of this workload (keyed on the kernel source's sha256), never
-        # from counters read in this process; under --gpus N > 1 the object describes rank 0's launches
-        roof["traffic_measured_in_run"] = False
+        # `traffic`: counters of this run's own rocprofv3 --pmc child passes (plain single-GPU runs), else the committed summary of
+        # this workload (keyed on the kernel source's sha256); under --gpus N > 1 the object describes rank 0's launches
+        roof["traffic_measured_in_run"] = measured is not None
         roof["rank"] = 0
     out = {
         "metric": "stereo pairs/sec @256x512 maxdisp=192 (stage-4)",

@@ -7,7 +7,7 @@ rm -rf "$O"; mkdir -p "$O"
 cd "$R"
 python -c "import __graft_entry__ as g; g.build(); print('build ok')" > "$O/build.log" 2>&1; tail -1 "$O/build.log"
 run() { # tag, bench args
-  python bench.py --no-cpu-baseline --no-pipelined $2 > "$O/$1.json" 2> "$O/$1.err"
+  python bench.py --no-cpu-baseline --no-pipelined --no-measure-traffic $2 > "$O/$1.json" 2> "$O/$1.err"
   python -c "
 import json
 try:

@@ -22,7 +22,7 @@ for B, H, W in ((3, 64, 256), (4, 256, 512), (2, 64, 256)):
     print(B, H, W, "bit-equal:", all(torch.equal(x, y) for x, y in zip(a, b)))
 PY
 run() {
-  python bench.py --no-cpu-baseline --no-pipelined $2 > "$O/$1.json" 2> "$O/$1.err"
+  python bench.py --no-cpu-baseline --no-pipelined --no-measure-traffic $2 > "$O/$1.json" 2> "$O/$1.err"
   python -c "
 import json
 try:
