@@ -7,8 +7,8 @@ import re
 
 from conftest import ROOT
 
-DOCS = ["DESIGN.md", "INTEGRATION.md", "README.md", "profiles/NOTES.md", "profiles/r04/README.md", "profiles/r05/README.md", "tools/README.md", "bench.py",
-        "include/lwsnet_hip.h", "lwsnet_amd/dist.py", "__graft_entry__.py", "tests/golden/kitti_pair/README.md"]
+DOCS = ["DESIGN.md", "INTEGRATION.md", "README.md", "profiles/NOTES.md", "profiles/r04/README.md", "profiles/r05/README.md", "profiles/r06/README.md", "tools/README.md", "bench.py",
+        "include/lwsnet_hip.h", "lwsnet_amd/dist.py", "lwsnet_amd/launch.py", "lwsnet_amd/inference.py", "__graft_entry__.py", "tests/golden/kitti_pair/README.md"]
 PAT = re.compile(r"(?<![\w/.])((?:profiles|tools|tests|oracle|lwsnet_amd|include)/[\w./*<>{},\-]+\.(?:py|sh|hip|md|txt|json|csv|npz|png|h|c)(?![\w]))")
 
 
