@@ -40,7 +40,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin; two streams on one queue serialise.
-# A forward uses 3 streams (the caller's + 2 handle-owned side streams); PyTorch, RCCL (under torchrun) and the lws_pool
+# A forward uses 2 streams (the caller's + the handle-owned side stream); PyTorch, RCCL (under torchrun) and the lws_pool
 # workers add theirs.  Measured r03 on one MI355X: under `torchrun --nproc-per-node 1` the default of 4 cost 12 % of every
 # step (0.563 vs 0.505 ms, with or without the gather) and the 4-worker pool 13 % (2,390 vs 2,740 pairs/s); 8 queues remove
 # both and leave the plain single-stream run unchanged (1,972 vs 1,975 pairs/s).  Read once, when HIP initialises.

@@ -80,7 +80,7 @@ int lws_set_tensor(lws_handle h, const char *key, const float *host, const int64
  * and before any function that takes a handle + stage. */
 int lws_finalize(lws_handle h);
 
-/* Pre-allocates the activation workspace for batches up to B pairs of H x W and creates the handle's side streams
+/* Pre-allocates the activation workspace for batches up to B pairs of H x W and creates the handle's side stream
  * and cross-stream events (unless option "side_streams" is 0), so that later calls allocate nothing (required before
  * hipGraph capture). */
 int lws_reserve(lws_handle h, int B, int H, int W);
@@ -245,8 +245,8 @@ int lws_clone(lws_handle src, lws_handle *out);
 /* A pool of `workers` host threads, each with its own clone of `model` and ONE HIP stream.  A batch-1 forward is a chain
  * of ~35 dependent launches (launch-latency-bound, ~345 us of host time to issue); the pool keeps `workers` of them in
  * flight so that they overlap on the device and their host cost runs in parallel.  Results are bit-identical to
- * lws_forward.  flags: 0, or LWS_POOL_SIDE_STREAMS to let every worker also use its per-handle side streams
- * (3 streams per worker; more streams than hardware queues makes throughput depend on the stream -> queue mapping).
+ * lws_forward.  flags: 0, or LWS_POOL_SIDE_STREAMS to let every worker also use its per-handle side stream
+ * (2 streams per worker; more streams than hardware queues makes throughput depend on the stream -> queue mapping).
  * `model` must outlive the pool. */
 typedef struct lws_pool *lws_pool_handle;
 #define LWS_POOL_SIDE_STREAMS 1

@@ -3,7 +3,7 @@
 Importing the package (any `import lwsnet_amd.<module>`) exports the two runtime switches every entry point of this build
 needs BEFORE HIP initialises -- the ROCm runtime reads them once, when the first HIP call creates its queues:
 
-* GPU_MAX_HW_QUEUES=8 -- ROCm maps HIP streams onto hardware queues round-robin (default 4); a forward uses 3 streams, PyTorch,
+* GPU_MAX_HW_QUEUES=8 -- ROCm maps HIP streams onto hardware queues round-robin (default 4); a forward uses 2 streams, PyTorch,
   RCCL and the lws_pool workers add theirs, and two streams on one queue serialise: under `torchrun` the default cost 12 % of
   every step, the 4-worker pool 13 % (profiles/NOTES.md, round 3);
 * HSA_ENABLE_IPC_MODE_LEGACY=0 -- the driver of this pool only supports dmabuf IPC; without it RCCL across processes fails with
