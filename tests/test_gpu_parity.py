@@ -1247,6 +1247,14 @@ def test_cli_directory_pipeline_writes_identical_files(dev, hip_lib, tmp_path):
         assert got == seq, f"--workers {w}: files differ from the sequential loop"
         st = inf.main.last_stats
         assert st["pairs"] == 12 and st["skipped"] == 1 and st["pairs_per_s"] > 0
+    # the slots are shared memory registered with HIP as pinned; where registration is refused the same pipeline stages through
+    # pinned tensors -- forced here, same files
+    os.environ["LWS_CLI_NO_HOST_REGISTER"] = "1"
+    try:
+        assert run("staged", "--workers", "2") == seq
+        assert inf.main.last_stats["shared_memory_pinned"] is False
+    finally:
+        del os.environ["LWS_CLI_NO_HOST_REGISTER"]
 
 
 def test_io_kernels_match_the_host_pipeline(dev, hip_lib):
