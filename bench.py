@@ -687,6 +687,8 @@ def worker(args):
                 "peak_note": "bf16 dense peak / 6 cross products" if split else
                              "nominal: 64 FLOP/clk/SIMD at 2.4 GHz; see clock_ghz for the clock this kernel held in this run",
                 "clock_ghz": round(clock_ghz, 4) if clock_ghz else None,
+                # the same achieved rate against the peak at the clock the kernel held (peak x clock / 2.4 GHz)
+                "frac_at_held_clock": round(achieved / (peak * clock_ghz / 2.4), 4) if clock_ghz else None,
                 **({"clock_ghz_per_rank": clock_per_rank} if clock_per_rank else {}),
                 "clock_note": "in-kernel clock of k_conv3d_mid16 (lws_clock_stamp: d s_memtime / d s_memrealtime x 100 MHz, median of "
                               "64 workgroups of the last stage-1 launch of 16 forwards issued right after the timed region); peak is "
