@@ -64,10 +64,32 @@ def disparity_to_color(disp):
     return _JET[d8]
 
 
+def encode_png(rgb):
+    """[H,W,3] uint8 -> PNG bytes: 8-bit RGB, filter type 0 on every row, one IDAT of zlib level 1 -- the speed end of what
+    `cv2.imwrite(path, img)` (inference.py:120,136; OpenCV's PNG default is compression level 1) stands for.  Lossless like any
+    PNG: what is compared is the decoded pixels (tests/test_gpu_parity.py::test_config1_*, tests/test_host_cpu.py).  PIL's own
+    encoder at the same level spends twice the time choosing row filters (23 vs 12 ms for a 368x1232 map of noise-like disparities),
+    which is most of what a host worker of the pipelined CLI does per pair."""
+    import struct
+    import zlib
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    if rgb.ndim != 3 or rgb.shape[2] != 3:
+        raise ValueError(f"encode_png wants [H,W,3] uint8, got {rgb.shape}")
+    h, w, _ = rgb.shape
+    raw = np.empty((h, 1 + 3 * w), np.uint8)
+    raw[:, 0] = 0                                   # filter type None
+    raw[:, 1:] = rgb.reshape(h, 3 * w)
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+            + chunk(b"IDAT", zlib.compress(raw.tobytes(), 1)) + chunk(b"IEND", b""))
+
+
 def save_png(path, rgb):
-    """inference.py:120,136 `cv2.imwrite(path, img)`: OpenCV's PNG default is compression level 1 (best speed); so is this.
-    (Lossless either way: the pixels are what is compared, tests/test_gpu_parity.py::test_config1_*.)"""
-    Image.fromarray(rgb).save(path, compress_level=1)
+    with open(path, "wb") as f:
+        f.write(encode_png(rgb))
 
 
 def read_pfm(path):

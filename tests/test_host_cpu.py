@@ -126,6 +126,24 @@ def test_colour_map_and_uint8_cast():
     assert np.array_equal(col[0, 1], lut[95]) and np.array_equal(col[0, 3], lut[0])   # truncation, wrap at 256
 
 
+def test_png_writer_roundtrips_through_pil(tmp_path):
+    """imageio.encode_png / save_png (the CLI's cv2.imwrite, inference.py:120,136): a valid 8-bit RGB PNG that PIL decodes back
+    to the same pixels -- random bytes, a smooth colour-mapped disparity, one pixel, odd sizes."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:41, 0:77]
+    cases = [rng.integers(0, 256, (368, 1232, 3), dtype=np.uint8), rng.integers(0, 256, (1, 1, 3), dtype=np.uint8),
+             rng.integers(0, 256, (7, 5, 3), dtype=np.uint8), imageio.disparity_to_color((3.0 * yy + 0.5 * xx).astype(np.float32))]
+    for i, a in enumerate(cases):
+        path = tmp_path / f"{i}.png"
+        imageio.save_png(str(path), a)
+        with Image.open(path) as im:
+            assert im.mode == "RGB" and im.size == (a.shape[1], a.shape[0])
+            assert np.array_equal(np.asarray(im), a)
+    with pytest.raises(ValueError):
+        imageio.encode_png(np.zeros((4, 4), np.uint8))
+
+
 def test_jet_table_is_opencvs_against_the_reference_pngs():
     """The reference's own reference/{1..4}.png (written by inference.py:114-120) are the golden: every pixel is one
     entry of cv2.COLORMAP_JET.  Fixture = their distinct colours + four raw crops (tools/make_jet_fixture.py)."""
