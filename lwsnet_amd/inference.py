@@ -74,6 +74,7 @@ def _host_worker(task_q, done_q, slot_names, H, W):
             shms[sid] = (shm, buf[:n_px].reshape(H, W, 3), buf[n_px:2 * n_px].reshape(H, W, 3), buf[2 * n_px:].reshape(H, W, 3))
         return shms[sid]
 
+    done_q.put(("ready", -1, -1, 0.0))                                  # interpreter up, numpy and PIL imported
     while True:
         task = task_q.get()
         if task is None:
@@ -214,6 +215,18 @@ def inference_pipelined(model, left_imgs, right_imgs, args, log):
             gpool.reserve(1, H, W)
             gpool.submit(slots[0].dev_lr[:1].zero_(), slots[0].dev_lr[1:].zero_(), out=slots[0].outs).result()
             torch.cuda.synchronize(dev)
+            ready, t_wait = 0, time.perf_counter()
+            while ready < N:                                            # every worker has started (spawn + imports: ~1 s, once)
+                try:
+                    msg = done_q.get(timeout=5.0)
+                except queue.Empty:
+                    if not all(pr.is_alive() for pr in procs) or time.perf_counter() - t_wait > 120.0:
+                        raise RuntimeError("the host worker processes did not start")
+                    continue
+                if msg[0] == "ready":
+                    ready += 1
+                else:
+                    raise RuntimeError(f"unexpected message from a host worker before its start-up: {msg[:3]}")
             t_begin = time.perf_counter()
             tf = threading.Thread(target=feeder, daemon=True)
             tc = threading.Thread(target=collector, daemon=True)
