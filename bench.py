@@ -282,7 +282,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-measure-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic in this run (single-GPU runs only); "
                          "the committed PMC summary of the same workload is reported instead")
-    ap.add_argument("--traffic-timeout", type=float, default=150.0, help="seconds one rocprofv3 --pmc child pass may take")
+    ap.add_argument("--traffic-timeout", type=float, default=60.0, help="seconds one rocprofv3 --pmc child pass may take")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)      # the child of _measure_traffic: timed steps only
     ap.add_argument("--config4-steps", type=int, default=None, help="timed steps of the config-4 leg (default: 10..50 following --steps)")
     return ap.parse_args(argv)
