@@ -141,7 +141,10 @@ int lws_clone(lws_handle src, lws_handle *out)
     h->params = src->params;             // shared, read-only; owned by src
     h->params_bytes = src->params_bytes;
     h->owns_params = false;
-    for (int i = 0; i < 3; ++i) h->stage[i] = src->stage[i];
+    for (int i = 0; i < 3; ++i) {
+        h->stage[i] = src->stage[i];
+        h->stage[i].clk = nullptr;       // (a clock stamp armed on the source stays the source's: lws_clock_stamp)
+    }
     h->net2d = src->net2d;
     h->have_2d = src->have_2d;
     h->finalized = true;
