@@ -152,3 +152,25 @@ def test_traffic_measurement_falls_back_without_a_gpu():
         pytest.skip("the fallback is what this test is about: needs a box without a GPU")
     measured, why = bench._measure_traffic(args)
     assert measured is None and isinstance(why, str) and why
+
+
+def test_launch_child_deadline_and_peer_failure():
+    """lwsnet_amd.launch.Child: a worker in its own process group is ended by the deadline, or as soon as a peer has failed,
+    and a worker that exits by itself reports its status and its JSON line."""
+    import time
+    from lwsnet_amd import launch
+    sleeper = [sys.executable, "-c", "import time; print('{\\"started\\": true}', flush=True); time.sleep(120)"]
+    t0 = time.monotonic()
+    c = launch.Child(sleeper, dict(os.environ))
+    ok, why = c.watch(time.monotonic() + 1.0)
+    assert not ok and "job timeout" in why and time.monotonic() - t0 < 15 and c.p.poll() is not None
+    assert c.json_lines() == ['{"started": true}']
+    c = launch.Child(sleeper, dict(os.environ))
+    ok, why = c.watch(time.monotonic() + 60.0, peer_failed=lambda: True)
+    assert not ok and why == "ended because another rank failed" and c.p.poll() is not None
+    c = launch.Child([sys.executable, "-c", "print('{\\"value\\": 1}'); raise SystemExit(0)"], dict(os.environ))
+    assert c.watch(time.monotonic() + 30.0) == (True, None) and c.json_lines() == ['{"value": 1}']
+    c = launch.Child([sys.executable, "-c", "raise SystemExit(7)"], dict(os.environ))
+    assert c.watch(time.monotonic() + 30.0) == (False, "worker exited with status 7")
+    d = json.loads(launch.error_line(8, 20, 5, "why"))
+    assert d["value"] is None and d["n_gpus"] == 8 and d["error"] == "why" and d["unit"] == "pairs/s"
