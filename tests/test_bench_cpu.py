@@ -159,7 +159,7 @@ def test_launch_child_deadline_and_peer_failure():
     and a worker that exits by itself reports its status and its JSON line."""
     import time
     from lwsnet_amd import launch
-    sleeper = [sys.executable, "-c", "import time; print('{\\"started\\": true}', flush=True); time.sleep(120)"]
+    sleeper = [sys.executable, "-c", "import json, time; print(json.dumps({'started': True}), flush=True); time.sleep(120)"]
     t0 = time.monotonic()
     c = launch.Child(sleeper, dict(os.environ))
     ok, why = c.watch(time.monotonic() + 1.0)
@@ -168,7 +168,7 @@ def test_launch_child_deadline_and_peer_failure():
     c = launch.Child(sleeper, dict(os.environ))
     ok, why = c.watch(time.monotonic() + 60.0, peer_failed=lambda: True)
     assert not ok and why == "ended because another rank failed" and c.p.poll() is not None
-    c = launch.Child([sys.executable, "-c", "print('{\\"value\\": 1}'); raise SystemExit(0)"], dict(os.environ))
+    c = launch.Child([sys.executable, "-c", "import json; print(json.dumps({'value': 1})); raise SystemExit(0)"], dict(os.environ))
     assert c.watch(time.monotonic() + 30.0) == (True, None) and c.json_lines() == ['{"value": 1}']
     c = launch.Child([sys.executable, "-c", "raise SystemExit(7)"], dict(os.environ))
     assert c.watch(time.monotonic() + 30.0) == (False, "worker exited with status 7")
