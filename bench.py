@@ -57,6 +57,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, 
 PEAK_BF16_MFMA_TFLOPS = 2516.6        # same table: 16 x the f32-input rate ("~2.5 PF dense")
 
 
+def _cpu_quota():
+    """The CPU quota the box gives this job (cgroup v2 cpu.max / v1 cfs quota), as the file says it; '?' when unreadable."""
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(f) as fh:
+                return fh.read().strip()
+        except OSError:
+            pass
+    return "?"
+
+
 def _sha256(path):
     import hashlib
     with open(path, "rb") as f:
@@ -803,7 +814,7 @@ def worker(args):
         e3 = error_3px(pred[3][:1].cpu().numpy(), np.maximum(ref[3].numpy(), 1e-3), 192)   # finetune.py:212-219, oracle as GT
         cpu = {"value": round(1.0 / med, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"3 forwards of 1 pair {H}x{W}, median, after probing 8/16/32/64 threads (host has {ncpu} logical "
-                         f"CPUs); literal oracle on torch-CPU {torch.__version__} (Paddle-CPU stand-in)",
+                         f"CPUs, cgroup cpu.max '{_cpu_quota()}'); literal oracle on torch-CPU {torch.__version__} (Paddle-CPU stand-in)",
                "max_abs_vs_gpu_per_stage": [round(e, 6) for e in err], "err_3px_stage4_vs_oracle": e3}
         # Numerics account (untimed): how far the GPU result and the float32 literal oracle each sit from the float64
         # literal oracle, per stage -- the smooth bench pair and a white-noise pair (the adversarial case).
