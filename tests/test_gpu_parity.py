@@ -711,16 +711,19 @@ def test_forward_odd_sizes(dev, model, H, W):
 
 
 @pytest.mark.parametrize("name,factor", [("e2e_64x256", 1.25), ("e2e_d32_64x320", 1.25), ("e2e_noise_64x256", 3.0),
-                                         ("e2e_args_32x256", 5.0)])
+                                         ("e2e_args_32x256", 5.0), ("e2e_align1_64x256", 1.25)])
 def test_forward_within_reference_source_noise_floor(dev, hip_lib, name, factor):
     """The gate VERDICT r1 asked for, on the GPU: per stage, |HIP - float64| <= factor x |reference source float32 - float64|
     (+1e-4 px), against the stage maps the reference's OWN source produced in float32 and float64
     (tests/golden/ref_source_*.npz, tools/check_oracle_vs_reference.py).  Factor 1.25 on the calibrated smooth pairs; the
-    white-noise pair and the uncalibrated-BatchNorm case compare single samples of a heavy-tailed maximum (3x / 5x)."""
+    white-noise pair and the uncalibrated-BatchNorm case compare single samples of a heavy-tailed maximum (3x / 5x).
+    `e2e_align1_64x256` is the reference's source under the OTHER reading of F.interpolate (align_mode = 1): the model is built
+    with interp_align_mode = 1 and held to the same gate against that fixture."""
     from lwsnet_amd.models import LWSNet
     g = golden(f"ref_source_{name}.npz")
     args = default_args(maxdisplist=tuple(int(v) for v in g["maxdisplist"]), layers_3d=int(g["layers_3d"]),
-                        channels_3d=int(g["channels_3d"]), growth_rate=tuple(int(v) for v in g["growth_rate"]))
+                        channels_3d=int(g["channels_3d"]), growth_rate=tuple(int(v) for v in g["growth_rate"]),
+                        interp_align_mode=int(g["align_mode"]) if "align_mode" in g else 0)
     sd = make_state_dict(int(g["seed"]), args, calibrated=bool(g["calibrated"]))
     m = LWSNet(args, device=dev).set_state_dict(sd).eval()
     pred = m(g["left"], g["right"])

@@ -108,7 +108,7 @@ def test_literal_forward_matches_golden(state_dict):
         np.testing.assert_allclose(pred[i].numpy(), g[f"pred{i}"], rtol=0, atol=1e-4)
 
 
-REF_SOURCE_CASES = ["e2e_64x256", "e2e_noise_64x256", "e2e_d32_64x320", "e2e_args_32x256", "e2e_odd_63x255"]
+REF_SOURCE_CASES = ["e2e_64x256", "e2e_noise_64x256", "e2e_d32_64x320", "e2e_args_32x256", "e2e_odd_63x255", "e2e_align1_64x256"]
 
 
 def _ref_case(name):
@@ -124,13 +124,20 @@ def _ref_case(name):
     return g, args, sd
 
 
+def _ref_variant(g):
+    """A fixture made under the other reading of F.interpolate says so (`align_mode`; ref_source_e2e_align1_64x256.npz): both
+    restatements are then run under the same reading -- what lws_config.interp_align_mode = 1 selects in the product."""
+    return O.variant(align_mode=int(g["align_mode"]) if "align_mode" in g else 0)
+
+
 @pytest.mark.parametrize("name", REF_SOURCE_CASES)
 def test_literal_oracle_equals_reference_source(name):
     """The hand restatement reproduces the reference source's stage maps bit for bit, in float32 and in float64
     (same torch-CPU kernels underneath, so any difference would be a transcription error)."""
     g, args, sd = _ref_case(name)
-    p32 = O.forward(g["left"], g["right"], sd, args.maxdisplist, torch.float32)
-    p64 = O.forward(g["left"], g["right"], sd, args.maxdisplist, torch.float64)
+    with _ref_variant(g):
+        p32 = O.forward(g["left"], g["right"], sd, args.maxdisplist, torch.float32)
+        p64 = O.forward(g["left"], g["right"], sd, args.maxdisplist, torch.float64)
     for i in range(4):
         assert np.array_equal(p32[i].numpy(), g[f"pred{i}"]), f"{name} float32 stage {i + 1}"
         assert np.array_equal(p64[i].numpy(), g[f"pred64_{i}"]), f"{name} float64 stage {i + 1}"
@@ -139,7 +146,8 @@ def test_literal_oracle_equals_reference_source(name):
 # (case, factor): max-abs is a heavy-tailed statistic of ONE noise sample; on the calibrated smooth pairs the two float32
 # runs sit within a few percent of each other, on the adversarial inputs (white-noise pair; uncalibrated BatchNorm
 # statistics, activations of 1e3) within a small factor.
-NOISE_GATE = [("e2e_64x256", 1.25), ("e2e_d32_64x320", 1.25), ("e2e_noise_64x256", 3.0), ("e2e_args_32x256", 5.0)]
+NOISE_GATE = [("e2e_64x256", 1.25), ("e2e_d32_64x320", 1.25), ("e2e_noise_64x256", 3.0), ("e2e_args_32x256", 5.0),
+              ("e2e_align1_64x256", 1.25)]
 
 
 @pytest.mark.parametrize("name,factor", NOISE_GATE)
@@ -148,7 +156,8 @@ def test_c_oracle_within_reference_noise_floor(name, factor):
     float64 run: per stage no further away than `factor` x what the reference source's OWN float32 run is (+1e-4 px).
     north_star's 1e-3 px at stage 4 is below that floor (2.7e-3 px here, 5e-3 px at 256x512): see DESIGN.md section 2."""
     g, args, sd = _ref_case(name)
-    got = C.forward(g["left"], g["right"], sd, args.maxdisplist)
+    with _ref_variant(g):
+        got = C.forward(g["left"], g["right"], sd, args.maxdisplist)
     for i in range(4):
         floor = float(np.abs(g[f"pred{i}"].astype(np.float64) - g[f"pred64_{i}"]).max())
         mine = float(np.abs(got[i].astype(np.float64) - g[f"pred64_{i}"]).max())

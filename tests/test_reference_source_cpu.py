@@ -20,7 +20,7 @@ pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "models", "
                                 or os.environ.get("LWS_SKIP_REFERENCE_SOURCE") == "1",
                                 reason="the reference tree is only mounted in the build container (or LWS_SKIP_REFERENCE_SOURCE=1)")
 
-NAMES = ["e2e_64x256", "e2e_args_32x256", "e2e_odd_63x255"]
+NAMES = ["e2e_64x256", "e2e_args_32x256", "e2e_odd_63x255", "e2e_align1_64x256"]
 
 
 def _tree_state(root):

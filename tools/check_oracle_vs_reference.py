@@ -61,6 +61,16 @@ CASES = [
     ("e2e_args_32x256", 32, 256, "smooth", dict(maxdisplist=(24, 3, 4), layers_3d=3, channels_3d=8, growth_rate=(2, 1, 1)), False),
     ("e2e_odd_63x255", 63, 255, "smooth", dict(), True),      # H, W = 8k-1: legal for the reference (ceil(H/2) % 4 == 0)
 ]
+# ... and one case under the OTHER reading of F.interpolate (align_mode = 1, src = ratio * dst): the stand-in and the
+# restatement share the switch (oracle.lws_oracle.VARIANT), the product has it as lws_config.interp_align_mode
+VARIANT_CASES = [("e2e_align1_64x256", 64, 256, "smooth", dict(), True, dict(align_mode=1))]
+
+
+def case_variant(name):
+    for c in VARIANT_CASES:
+        if c[0] == name:
+            return c[6]
+    return {}
 
 
 def run_reference(ref_root, args, sd, left, right, dtype):
@@ -189,7 +199,8 @@ def check_fixtures(ref_root, names):
         args = default_args(maxdisplist=tuple(int(v) for v in g["maxdisplist"]), layers_3d=int(g["layers_3d"]),
                             channels_3d=int(g["channels_3d"]), growth_rate=tuple(int(v) for v in g["growth_rate"]))
         sd = make_state_dict(int(g["seed"]), args, calibrated=bool(g["calibrated"]))
-        out, keys = run_reference(ref_root, args, sd, g["left"], g["right"], torch.float32)
+        with O.variant(**case_variant(name)):            # (a fixture made under another reading of Paddle's defaults says so)
+            out, keys = run_reference(ref_root, args, sd, g["left"], g["right"], torch.float32)
         ok = keys == sorted(sd.keys()) and all(np.array_equal(out[i], g[f"pred{i}"]) for i in range(4))
         print(f"{name}: {'OK' if ok else 'DIFFERS'} (226 structured names {'match' if keys == sorted(sd.keys()) else 'DIFFER'})")
         bad += 0 if ok else 1
@@ -212,7 +223,8 @@ def main():
     if a.check_fixtures:
         return 1 if check_fixtures(a.reference, a.check_fixtures) else 0
     worst = 0.0
-    for name, H, W, kind, kw, calib in CASES:
+    for name, H, W, kind, kw, calib, *var in CASES + VARIANT_CASES:
+        var = var[0] if var else {}
         args = default_args(**kw)
         sd = make_state_dict(7, args, calibrated=calib)
         if kind == "noise":
@@ -220,11 +232,12 @@ def main():
         else:
             l, r, _ = make_pair(H, W, 0)
         l, r = l[None], r[None]
-        ref32, keys = run_reference(a.reference, args, sd, l, r, torch.float32)
-        ref64, _ = run_reference(a.reference, args, sd, l, r, torch.float64)
-        assert keys == sorted(sd.keys()), "state-dict names differ from the reference's own layers"
-        ora32 = [p.numpy() for p in O.forward(l, r, sd, args.maxdisplist, torch.float32)]
-        ora64 = [p.numpy() for p in O.forward(l, r, sd, args.maxdisplist, torch.float64)]
+        with O.variant(**var):
+            ref32, keys = run_reference(a.reference, args, sd, l, r, torch.float32)
+            ref64, _ = run_reference(a.reference, args, sd, l, r, torch.float64)
+            assert keys == sorted(sd.keys()), "state-dict names differ from the reference's own layers"
+            ora32 = [p.numpy() for p in O.forward(l, r, sd, args.maxdisplist, torch.float32)]
+            ora64 = [p.numpy() for p in O.forward(l, r, sd, args.maxdisplist, torch.float64)]
         d32 = [float(np.abs(x - y).max()) for x, y in zip(ref32, ora32)]
         d64 = [float(np.abs(x - y).max()) for x, y in zip(ref64, ora64)]
         n32 = [float(np.abs(x.astype(np.float64) - y).max()) for x, y in zip(ref32, ref64)]
@@ -235,6 +248,7 @@ def main():
             out = os.path.join(ROOT, "tests", "golden", f"ref_source_{name}.npz")
             np.savez_compressed(out, left=l, right=r, seed=7, calibrated=calib, maxdisplist=np.array(args.maxdisplist),
                                 layers_3d=args.layers_3d, channels_3d=args.channels_3d, growth_rate=np.array(args.growth_rate),
+                                align_mode=int(var.get("align_mode", 0)),
                                 **{f"pred{i}": p.astype(np.float32) for i, p in enumerate(ref32)},
                                 **{f"pred64_{i}": p.astype(np.float64) for i, p in enumerate(ref64)})
             print("  wrote", out, os.path.getsize(out))
